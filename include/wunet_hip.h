@@ -1,0 +1,98 @@
+/*
+ * C ABI of the MI355X-native Wave-U-Net hot path (libwunet_hip.so, gfx950).
+ *
+ * The reference (haoxiangsnr/Wave-U-Net-for-Speech-Enhancement) is pure Python: its "FFI" for
+ * this path is torch's dispatcher.  These entry points are what a maintainer binds instead
+ * (ctypes stub in INTEGRATION.md); each cites the reference interface it replaces.
+ * All pointers are DEVICE pointers (hipMalloc'ed / torch caching allocator) unless noted, fp32,
+ * layout (batch, channel, sample) contiguous.  `stream` is a hipStream_t (NULL = default stream).
+ * Every function returns 0 on success and a negative code on failure; wunet_last_error() gives text.
+ * Nothing here synchronises the stream: calls only enqueue kernels.
+ *
+ * Parameter order ("canonical order", == nn.Module.parameters() order of the reference Model,
+ * model/unet_basic.py:33-75): for each conv layer in forward order
+ * [encoder.0 .. encoder.n-1, middle, decoder.0 .. decoder.n-1]:
+ *   conv.weight [Cout,Cin,K], conv.bias [Cout], bn.weight [Cout], bn.bias [Cout];
+ * then out.0.weight [1,ci+1,1], out.0.bias [1].   -> 4*(2n+1)+2 pointers.
+ * Running statistics: 2*(2n+1) pointers (running_mean, running_var per layer);
+ * num_batches_tracked: (2n+1) int64 device pointers.
+ */
+#ifndef WUNET_HIP_H
+#define WUNET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wunet_ctx wunet_ctx;
+
+#define WUNET_OK 0
+#define WUNET_E_ARG (-1)        /* bad argument / unsupported shape */
+#define WUNET_E_RUNTIME (-2)    /* HIP runtime error */
+
+#define WUNET_LOSS_MSE 0        /* model/loss.py:3-4  torch.nn.MSELoss()      */
+#define WUNET_LOSS_L1 1         /* model/loss.py:6-7  torch.nn.L1Loss()       */
+#define WUNET_LOSS_SMOOTH_L1 2  /* torch.nn.SmoothL1Loss(beta=1), SURVEY.md §0 */
+
+const char* wunet_last_error(void);
+
+/* Replaces Model.__init__ shape bookkeeping (model/unet_basic.py:33-75) for one (batch, length).
+ * length must be a power of two with length >> n_layers >= 4.  Host-side object, no device memory. */
+int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out);
+void wunet_destroy(wunet_ctx* ctx);
+
+/* Bytes of device workspace the caller must provide to wunet_forward (with_backward=0: inference;
+ * with_backward=1: also holds everything wunet_backward needs). */
+size_t wunet_workspace_bytes(const wunet_ctx* ctx, int with_backward);
+
+/* Replaces Model.forward (model/unet_basic.py:77-100).
+ * training != 0: BatchNorm uses batch statistics and updates running_mean/var (momentum 0.1,
+ * unbiased variance) and num_batches_tracked in place; otherwise running statistics are used.
+ * The workspace keeps the raw conv outputs and BN statistics for wunet_backward. */
+int wunet_forward(wunet_ctx* ctx, const float* noisy, const float* const* params,
+                  float* const* running, long long* const* num_batches_tracked, int training,
+                  void* workspace, float* enhanced, void* stream);
+
+/* Replaces autograd's backward of Model.forward (trainer/trainer.py:37 loss.backward()).
+ * Must follow a training-mode wunet_forward on the same ctx/workspace/params/noisy.
+ * grad_enhanced: dL/d(enhanced) [B,1,T].  grads: same shapes/order as params; every tensor is
+ * overwritten (conv biases feeding training-mode BatchNorm get an exact 0).  No input gradient. */
+int wunet_backward(wunet_ctx* ctx, const float* noisy, const float* const* params,
+                   const float* enhanced, const float* grad_enhanced, void* workspace,
+                   float* const* grads, void* stream);
+/* Same as wunet_backward but only runs conv layers [layer_begin, layer_end) in backward order
+ * (layer index in forward order; the output head belongs to layer 2n).  Lets the caller overlap the
+ * RCCL all-reduce of finished gradient buckets with the remaining layers. */
+int wunet_backward_range(wunet_ctx* ctx, const float* noisy, const float* const* params,
+                         const float* enhanced, const float* grad_enhanced, void* workspace,
+                         float* const* grads, int layer_begin, int layer_end, void* stream);
+
+/* Replaces loss_function(clean, enhanced) (trainer/trainer.py:36; model/loss.py:3-7), mean reduction.
+ * scratch: >= wunet_loss_scratch_bytes() device bytes.  loss_out: device float. */
+size_t wunet_loss_scratch_bytes(void);
+int wunet_loss_forward(int kind, const float* clean, const float* enhanced, size_t n,
+                       float* loss_out, void* scratch, void* stream);
+/* grad_enhanced[i] = grad_loss[0] * d loss / d enhanced[i]  (grad_loss: device float, usually 1). */
+int wunet_loss_backward(int kind, const float* clean, const float* enhanced, const float* grad_loss,
+                        size_t n, float* grad_enhanced, void* stream);
+
+/* Introspection for tests / profiling: float offset of layer i's raw conv output inside the
+ * workspace, its channel count and length. */
+int wunet_layer_info(const wunet_ctx* ctx, int layer, size_t* z_offset_floats, int* channels, int* length);
+int wunet_num_conv_layers(const wunet_ctx* ctx);
+
+/* Single-op entry points (parity tests of the MFMA kernels against F.conv1d semantics,
+ * nn.Conv1d stride 1, padding K/2, K in {5, 15}).  They allocate scratch and synchronise. */
+int wunet_op_conv1d(const float* x, const float* w, const float* bias, float* z,
+                    int B, int Cin, int Cout, int L, int K, void* stream);
+int wunet_op_conv1d_dgrad(const float* gz, const float* w, float* dx,
+                          int B, int Cin, int Cout, int L, int K, void* stream);
+int wunet_op_conv1d_wgrad(const float* gz, const float* x, float* dw,
+                          int B, int Cin, int Cout, int L, int K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

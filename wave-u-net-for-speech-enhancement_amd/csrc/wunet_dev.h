@@ -1,0 +1,45 @@
+// Device-side vocabulary of the Wave-U-Net HIP kernels.
+//
+// Product build (hipcc --offload-arch=gfx950): plain HIP + CDNA4 builtins.
+// Test build   (g++ -DWUNET_EMU, tests/emu/): the same kernel sources run on a CPU fiber
+// emulator of a 256-thread workgroup (64-lane waves, LDS, s_barrier, the fp32 MFMA lane
+// layout) so index math can be validated in the GPU-less build container.  The emulator is
+// test infrastructure: the package never loads it.
+#pragma once
+
+#ifdef WUNET_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#define WUNET_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+typedef float wunet_f4 __attribute__((ext_vector_type(4)));
+// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact fp32 fma chain.
+// lane l holds A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D[row=(l>>4)*4+r][col=l&15] in reg r.
+__device__ __forceinline__ wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float wunet_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+#endif
+
+#define WUNET_THREADS 256
+#define WUNET_WAVES 4
+#define WUNET_SLOPE 0.1f
+
+__device__ __forceinline__ float wunet_lrelu(float v) { return v > 0.0f ? v : WUNET_SLOPE * v; }
+
+// ATen upsample_linear1d(align_corners=True) source coordinate, fp32 arithmetic on purpose
+// (reference model/unet_basic.py:93 -> ATen UpSample.h area_pixel_compute_source_index +
+// guard_index_and_lambda).  scale = (float)(Lin-1)/(Lout-1) is computed on the host the same way.
+__device__ __forceinline__ void wunet_up_coord(int j, int Lin, float scale, int& i0, int& i1, float& l0, float& l1)
+{
+    const float src = scale * (float)j;
+    int a = (int)floorf(src);
+    a = a > Lin - 1 ? Lin - 1 : a;
+    float lam = src - (float)a;
+    lam = lam < 0.0f ? 0.0f : (lam > 1.0f ? 1.0f : lam);
+    i0 = a;
+    i1 = a + (a < Lin - 1 ? 1 : 0);
+    l1 = lam;
+    l0 = 1.0f - lam;
+}

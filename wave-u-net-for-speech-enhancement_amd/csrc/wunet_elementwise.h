@@ -1,0 +1,389 @@
+// Memory-bound kernels of the Wave-U-Net hot path: weight packing, BatchNorm statistics
+// finalisation (forward and backward), the output head, the gradient-assembly pass
+// ("pass A": upsample^T / zero-stuffed decimation^T / skip add + LeakyReLU' + BN-backward sums),
+// split-K reduction of weight gradients, and the losses.
+#pragma once
+#include "wunet_dev.h"
+
+// ---------------------------------------------------------------------------- weight packing
+// One descriptor per (layer, direction).  dst[mt][c][t][i] = W[o = mt*16+i][c][t] (forward) or the
+// flipped/transposed tensor for the data gradient: dst[mt][c][t][i] = W[co = c][ci = mt*16+i][TAPS-1-t].
+struct PackDesc {
+    const float* w;   // reference layout [Cout][Cin][TAPS]
+    float* dst;       // [Mtiles][CP][TAPS][16]
+    int Cout, Cin, taps;
+    int M;            // rows of the packed GEMM (Cout forward, Cin for dgrad)
+    int CP;           // padded K-channel count
+    int mtiles;       // padded m-tile count
+    int transposed;   // 0 forward, 1 dgrad
+};
+
+#define WUNET_MAX_CONV_LAYERS 34
+struct PackTable { PackDesc d[WUNET_MAX_CONV_LAYERS]; };
+
+__global__ __launch_bounds__(WUNET_THREADS) void pack_weights_kernel(PackTable tab)
+{
+    const PackDesc& d = tab.d[blockIdx.y];
+    const int total = d.mtiles * d.CP * d.taps * 16;
+    const int kc = d.transposed ? d.Cout : d.Cin;   // valid K-channels
+    for (int idx = blockIdx.x * WUNET_THREADS + threadIdx.x; idx < total; idx += gridDim.x * WUNET_THREADS) {
+        const int i = idx & 15;
+        int r = idx >> 4;
+        const int t = r % d.taps; r /= d.taps;
+        const int c = r % d.CP;
+        const int mt = r / d.CP;
+        const int m = mt * 16 + i;
+        float v = 0.0f;
+        if (m < d.M && c < kc) {
+            v = d.transposed ? d.w[((size_t)c * d.Cin + m) * d.taps + (d.taps - 1 - t)]
+                             : d.w[((size_t)m * d.Cin + c) * d.taps + t];
+        }
+        d.dst[idx] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------- block reduce helper
+// sums two doubles over the 256-thread block; result valid in thread 0. red = 2*WUNET_THREADS doubles of LDS.
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* red)
+{
+    const int tid = threadIdx.x;
+    red[tid] = a;
+    red[WUNET_THREADS + tid] = b;
+    __syncthreads();
+    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            red[tid] += red[tid + s];
+            red[WUNET_THREADS + tid] += red[WUNET_THREADS + tid + s];
+        }
+        __syncthreads();
+    }
+    a = red[0];
+    b = red[WUNET_THREADS];
+}
+
+// ---------------------------------------------------------------------------- BN forward finalize
+// grid = C.  Training: reduce the conv epilogue partials (bias-free sums) -> batch mean / biased var,
+// scale/shift for the consumers, saved mean/rstd for backward, running-stat update (unbiased var,
+// momentum 0.1) and num_batches_tracked += 1 (nn.BatchNorm1d defaults, reference unet_basic.py:12,25,55).
+// Eval: scale/shift from the running statistics.
+struct BnFwdArgs {
+    const float* stats;   // [rows][C][2] or nullptr (eval)
+    int rows;
+    const float* bias;    // conv bias [C]
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    long long* nbt;
+    float* a;             // out: scale  gamma*rstd
+    float* s;             // out: shift  beta - mean*a
+    float* mean;          // out (training): batch mean of z
+    float* rstd;          // out (training)
+    int C;
+    double count;         // B*L
+    int training;
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArgs A)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    if (!A.training) {
+        if (tid == 0) {
+            const float rstd = (float)(1.0 / sqrt((double)A.running_var[c] + 1e-5));
+            const float a = A.gamma[c] * rstd;
+            A.a[c] = a;
+            A.s[c] = A.beta[c] - A.running_mean[c] * a;
+        }
+        return;
+    }
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = tid; r < A.rows; r += WUNET_THREADS) {
+        const float* st = A.stats + ((size_t)r * A.C + c) * 2;
+        s1 += (double)st[0];
+        s2 += (double)st[1];
+    }
+    block_sum2(s1, s2, red);
+    if (tid == 0) {
+        const double m0 = s1 / A.count;                   // mean of the bias-free conv
+        double var = s2 / A.count - m0 * m0;              // biased variance (bias does not change it)
+        var = var < 0.0 ? 0.0 : var;
+        const double mean = m0 + (double)A.bias[c];
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float a = A.gamma[c] * rstd;
+        A.a[c] = a;
+        A.s[c] = A.beta[c] - (float)mean * a;
+        A.mean[c] = (float)mean;
+        A.rstd[c] = rstd;
+        const double unbiased = A.count > 1.0 ? var * A.count / (A.count - 1.0) : var;
+        A.running_mean[c] = (float)(0.9 * (double)A.running_mean[c] + 0.1 * mean);
+        A.running_var[c] = (float)(0.9 * (double)A.running_var[c] + 0.1 * unbiased);
+        if (c == 0) *A.nbt += 1;
+    }
+}
+
+// ---------------------------------------------------------------------------- output head forward
+// out[b,l] = tanh(bh + sum_c wh[c]*lrelu(a[c]*z[b,c,l]+s[c]) + wh[C]*in[b,l])
+// (reference unet_basic.py:98-99: cat([o, input]) -> Conv1d(C+1 -> 1, k=1) -> Tanh)
+struct HeadFwdArgs {
+    const float* z;    // [B][C][T] raw conv output of the last decoder layer
+    const float* a;
+    const float* s;
+    const float* in;   // [B][T]
+    const float* wh;   // [C+1]
+    const float* bh;   // [1]
+    float* out;        // [B][T]
+    int B, C, T, logT;
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void head_fwd_kernel(HeadFwdArgs A)
+{
+    const size_t total = (size_t)A.B * A.T;
+    for (size_t p = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; p < total; p += (size_t)gridDim.x * WUNET_THREADS) {
+        const size_t b = p >> A.logT, t = p & (size_t)(A.T - 1);
+        float acc = A.bh[0];
+        const float* zr = A.z + b * A.C * A.T + t;
+        for (int c = 0; c < A.C; ++c) acc += A.wh[c] * wunet_lrelu(A.a[c] * zr[(size_t)c * A.T] + A.s[c]);
+        acc += A.wh[A.C] * A.in[p];
+        A.out[p] = tanhf(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------- output head backward
+// gh = gout * (1 - out^2); partial sums for d wh[c] = sum gh*y_c (c<C), d wh[C] = sum gh*in, d bh = sum gh.
+// grid = (nblk); partial layout part[blk][C+2].
+struct HeadBwdArgs {
+    const float* z; const float* a; const float* s; const float* in;
+    const float* out; const float* gout;
+    float* gh;        // [B][T]
+    float* part;      // [gridDim.x][C+2]
+    int B, C, T, logT;
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdArgs A)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    const size_t total = (size_t)A.B * A.T;
+    const size_t per = (total + gridDim.x - 1) / gridDim.x;
+    const size_t beg = (size_t)blockIdx.x * per, end = beg + per < total ? beg + per : total;
+    // pass 1: gh and the two channel-free sums
+    double sb = 0.0, sin_ = 0.0;
+    for (size_t p = beg + threadIdx.x; p < end; p += WUNET_THREADS) {
+        const float o = A.out[p];
+        const float g = A.gout[p] * (1.0f - o * o);
+        A.gh[p] = g;
+        sb += (double)g;
+        sin_ += (double)g * (double)A.in[p];
+    }
+    block_sum2(sb, sin_, red);
+    if (threadIdx.x == 0) {
+        A.part[(size_t)blockIdx.x * (A.C + 2) + A.C] = (float)sin_;
+        A.part[(size_t)blockIdx.x * (A.C + 2) + A.C + 1] = (float)sb;
+    }
+    __syncthreads();
+    // pass 2: per-channel sums (gh re-read from this block's own writes: same threads, same addresses)
+    for (int c = 0; c < A.C; c += 2) {
+        double s0 = 0.0, s1 = 0.0;
+        for (size_t p = beg + threadIdx.x; p < end; p += WUNET_THREADS) {
+            const size_t b = p >> A.logT, t = p & (size_t)(A.T - 1);
+            const float g = A.gh[p];
+            const float* zr = A.z + b * A.C * A.T + t;
+            s0 += (double)(g * wunet_lrelu(A.a[c] * zr[(size_t)c * A.T] + A.s[c]));
+            if (c + 1 < A.C) s1 += (double)(g * wunet_lrelu(A.a[c + 1] * zr[(size_t)(c + 1) * A.T] + A.s[c + 1]));
+        }
+        __syncthreads();
+        block_sum2(s0, s1, red);
+        if (threadIdx.x == 0) {
+            A.part[(size_t)blockIdx.x * (A.C + 2) + c] = (float)s0;
+            if (c + 1 < A.C) A.part[(size_t)blockIdx.x * (A.C + 2) + c + 1] = (float)s1;
+        }
+        __syncthreads();
+    }
+}
+
+// sums partial rows: out[j] = sum_r part[r][j]   (grid = ceil(n/256))
+__global__ __launch_bounds__(WUNET_THREADS) void rows_sum_kernel(const float* part, int rows, int n, float* out0, int n0, float* out1)
+{
+    const int j = blockIdx.x * WUNET_THREADS + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * n + j];
+    if (j < n0) out0[j] = (float)s; else out1[j - n0] = (float)s;
+}
+
+// ---------------------------------------------------------------------------- pass A (gradient assembly)
+// Builds g_pre = dL/d(BN output) of one layer from its consumers' data gradients, applies the
+// LeakyReLU derivative, writes g_pre and the partial sums  sum g_pre, sum g_pre*xhat  per channel.
+//   A_HEAD : g_y[b,c,l] = wh[c] * gh[b,l]                                  (last decoder layer)
+//   A_UP   : g_y[b,c,i] = sum_j w(j->i) dX[b,c,j], dX of the next decoder layer at 2L, upsample^T
+//   A_ENC  : g_y[b,c,l] = dXdec[b, coff+c, l] + (l even ? dXenc[b,c,l/2] : 0)   (skip + decimation^T)
+// grid = (C, nsplit); part[split][C][2].
+enum { A_HEAD = 0, A_UP = 1, A_ENC = 2 };
+struct PassAArgs {
+    const float* z;      // [B][C][L]
+    const float* a;      // scale/shift of this layer (sign of the pre-activation)
+    const float* s;
+    const float* mean;
+    const float* rstd;
+    float* gpre;         // out [B][C][L]
+    float* part;         // [nsplit][C][2]
+    const float* g0;     // HEAD: gh [B][L];  UP: dX [B][Cg0][2L];  ENC: dXdec [B][Cg0][L]
+    const float* g1;     // HEAD: wh;         ENC: dXenc [B][C][L/2]
+    int Cg0;             // channel count of the g0 tensor
+    int coff;            // ENC: channel offset of the skip part inside dXdec
+    int B, C, L, logL;
+    float up_scale;      // UP: (float)(L-1)/(2L-1)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    const int c = blockIdx.x;
+    const size_t total = (size_t)A.B * A.L;
+    const size_t per = (total + gridDim.y - 1) / gridDim.y;
+    const size_t beg = (size_t)blockIdx.y * per, end = beg + per < total ? beg + per : total;
+    const float a = A.a[c], s = A.s[c], mu = A.mean[c], rstd = A.rstd[c];
+    const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
+    double s1 = 0.0, s2 = 0.0;
+    for (size_t p = beg + threadIdx.x; p < end; p += WUNET_THREADS) {
+        const int b = (int)(p >> A.logL), l = (int)(p & (size_t)(A.L - 1));
+        const size_t zi = ((size_t)b * A.C + c) * A.L + l;
+        const float z = A.z[zi];
+        float g;
+        if (MODE == A_HEAD) {
+            g = wh * A.g0[(size_t)b * A.L + l];
+        } else if (MODE == A_ENC) {
+            g = A.g0[((size_t)b * A.Cg0 + A.coff + c) * A.L + l];
+            if ((l & 1) == 0) g += A.g1[((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1)];
+        } else {
+            // transpose of ATen's upsample_linear1d: every output j in [2l-2, 2l+2] whose fp32-computed
+            // source indices hit l contributes (ascending j, same order as ATen's backward loop)
+            const int Lo = 2 * A.L;
+            const float* row = A.g0 + ((size_t)b * A.Cg0 + c) * Lo;
+            g = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int j = 2 * l - 2 + k;
+                if (j >= 0 && j < Lo) {
+                    int i0, i1; float l0, l1;
+                    wunet_up_coord(j, A.L, A.up_scale, i0, i1, l0, l1);
+                    const float w = (i0 == l ? l0 : 0.0f) + (i1 == l ? l1 : 0.0f);
+                    if (w != 0.0f) g += w * row[j];
+                }
+            }
+        }
+        if (!(a * z + s > 0.0f)) g *= WUNET_SLOPE;
+        A.gpre[zi] = g;
+        s1 += (double)g;
+        s2 += (double)(g * ((z - mu) * rstd));
+    }
+    block_sum2(s1, s2, red);
+    if (threadIdx.x == 0) {
+        float* pr = A.part + ((size_t)blockIdx.y * A.C + c) * 2;
+        pr[0] = (float)s1;
+        pr[1] = (float)s2;
+    }
+}
+
+// ---------------------------------------------------------------------------- BN backward finalize
+// grid = C.  dgamma = sum g*xhat, dbeta = sum g, and the folded coefficients of
+// g_z = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)) = k1*g + k2*z + k3.
+struct BnBwdArgs {
+    const float* part; int rows;
+    const float* gamma; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta;
+    float* k1; float* k2; float* k3;
+    int C; double count;
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArgs A)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = tid; r < A.rows; r += WUNET_THREADS) {
+        const float* pr = A.part + ((size_t)r * A.C + c) * 2;
+        s1 += (double)pr[0];
+        s2 += (double)pr[1];
+    }
+    block_sum2(s1, s2, red);
+    if (tid == 0) {
+        A.dgamma[c] = (float)s2;
+        A.dbeta[c] = (float)s1;
+        const double m1 = s1 / A.count, m2 = s2 / A.count;
+        const double a = (double)A.gamma[c] * (double)A.rstd[c];
+        A.k1[c] = (float)a;
+        A.k2[c] = (float)(-a * m2 * (double)A.rstd[c]);
+        A.k3[c] = (float)(a * m2 * (double)A.rstd[c] * (double)A.mean[c] - a * m1);
+    }
+}
+
+// ---------------------------------------------------------------------------- split-K reduce of dW
+__global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float* part, int splits, size_t n, float* dw)
+{
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
+        float s = 0.0f;
+        int r = 0;
+        // pairwise-ish: sum groups of 8 in fp32, groups in double (deterministic, fixed order)
+        double tot = 0.0;
+        for (; r + 8 <= splits; r += 8) {
+            s = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += part[(size_t)(r + k) * n + i];
+            tot += (double)s;
+        }
+        for (; r < splits; ++r) tot += (double)part[(size_t)r * n + i];
+        dw[i] = (float)tot;
+    }
+}
+
+__global__ __launch_bounds__(WUNET_THREADS) void fill_kernel(float* p, size_t n, float v)
+{
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------- losses
+// loss(clean, enhanced) of trainer/trainer.py:36; kind 0 = MSELoss, 1 = L1Loss (model/loss.py:3-7),
+// 2 = SmoothL1Loss(beta=1).  mean reduction.
+__device__ __forceinline__ float loss_term(int kind, float d)
+{
+    if (kind == 0) return d * d;
+    const float ad = fabsf(d);
+    if (kind == 1) return ad;
+    return ad < 1.0f ? 0.5f * d * d : ad - 0.5f;
+}
+__device__ __forceinline__ float loss_dterm(int kind, float d)   // derivative w.r.t. d = enhanced - clean
+{
+    if (kind == 0) return 2.0f * d;
+    const float sg = (d > 0.0f ? 1.0f : 0.0f) - (d < 0.0f ? 1.0f : 0.0f);
+    if (kind == 1) return sg;
+    return fabsf(d) < 1.0f ? d : sg;
+}
+
+__global__ __launch_bounds__(WUNET_THREADS) void loss_partial_kernel(int kind, const float* clean, const float* enh, size_t n, double* part)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    double s = 0.0, dummy = 0.0;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS)
+        s += (double)loss_term(kind, enh[i] - clean[i]);
+    block_sum2(s, dummy, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(WUNET_THREADS) void loss_final_kernel(const double* part, int rows, size_t n, float* loss)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    double s = 0.0, dummy = 0.0;
+    for (int r = threadIdx.x; r < rows; r += WUNET_THREADS) s += part[r];
+    block_sum2(s, dummy, red);
+    if (threadIdx.x == 0) *loss = (float)(s / (double)n);
+}
+
+// grad_enh[i] = gscale[0] * dterm(enh - clean) / n
+__global__ __launch_bounds__(WUNET_THREADS) void loss_bwd_kernel(int kind, const float* clean, const float* enh, const float* gscale, size_t n, float* genh)
+{
+    const float sc = gscale[0] / (float)n;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS)
+        genh[i] = sc * loss_dterm(kind, enh[i] - clean[i]);
+}

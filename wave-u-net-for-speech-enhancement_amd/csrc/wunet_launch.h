@@ -1,0 +1,24 @@
+// Launch plumbing shared by the host API and the per-(taps, mode) instantiation units.
+#pragma once
+#include "wunet_kernels.h"
+
+#ifdef WUNET_EMU
+#define WUNET_LAUNCH(kern, grid, block, smem, stream, ...) emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
+#else
+#define WUNET_LAUNCH(kern, grid, block, smem, stream, ...) hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+#endif
+
+// One translation unit per (taps, loader mode) keeps hipcc builds parallel.  Return 0 when a kernel
+// for (mrep, nrep) exists and was enqueued, -1 otherwise.
+#define WUNET_DECL_CONV(T, M) int wunet_launch_conv_##T##_##M(const ConvArgs& a, int mrep, int nrep, dim3 grid, size_t smem, hipStream_t st)
+#define WUNET_DECL_WGRAD(T, M) int wunet_launch_wgrad_##T##_##M(const WgradArgs& a, int mrep, dim3 grid, size_t smem, hipStream_t st)
+WUNET_DECL_CONV(15, 0);
+WUNET_DECL_CONV(15, 1);
+WUNET_DECL_CONV(5, 2);
+WUNET_DECL_CONV(15, 3);
+WUNET_DECL_CONV(5, 3);
+WUNET_DECL_CONV(5, 0);
+WUNET_DECL_WGRAD(15, 0);
+WUNET_DECL_WGRAD(15, 1);
+WUNET_DECL_WGRAD(5, 2);
+WUNET_DECL_WGRAD(5, 0);

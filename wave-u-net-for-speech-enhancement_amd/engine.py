@@ -1,0 +1,150 @@
+"""Python face of the C ABI: owns per-shape contexts, turns torch tensors into raw device pointers
+and enqueues the HIP path on torch's current stream.  PyTorch is plumbing here (device memory,
+streams); every arithmetic kernel lives in csrc/."""
+import ctypes
+import threading
+
+import torch
+
+from . import _lib
+
+LOSS_KINDS = {"mse": 0, "l1": 1, "smooth_l1": 2}
+
+
+class WunetError(RuntimeError):
+    pass
+
+
+class Engine:
+    """One per process is enough (see `default_engine`).  `lib`/`host_memory` exist so the CPU test
+    suite can drive the same host logic against the emulator build with CPU tensors; product code
+    never passes them."""
+
+    def __init__(self, lib=None, host_memory=False):
+        self.lib = lib if lib is not None else _lib.load_hip()
+        self.host_memory = host_memory
+        self._ctx = {}
+        self._lock = threading.Lock()
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc):
+        if rc != 0:
+            raise WunetError(f"wunet error {rc}: {self.lib.wunet_last_error().decode()}")
+
+    def _ctx_for(self, n_layers, ci, batch, length):
+        key = (n_layers, ci, batch, length)
+        with self._lock:
+            h = self._ctx.get(key)
+            if h is None:
+                h = ctypes.c_void_p()
+                self._check(self.lib.wunet_create(n_layers, ci, batch, length, ctypes.byref(h)))
+                self._ctx[key] = h
+        return h
+
+    def _require(self, t, name):
+        if t.dtype != torch.float32 and t.dtype != torch.int64:
+            raise WunetError(f"{name}: expected float32, got {t.dtype}")
+        if not t.is_contiguous():
+            raise WunetError(f"{name}: tensor must be contiguous")
+        if self.host_memory:
+            if t.device.type != "cpu":
+                raise WunetError(f"{name}: emulator engine takes CPU tensors")
+        elif t.device.type != "cuda":
+            raise WunetError(f"{name}: the HIP path needs tensors on an MI355X (got device {t.device}); "
+                             "there is no CPU fallback")
+
+    def _stream(self, device):
+        if self.host_memory:
+            return None
+        return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    @staticmethod
+    def _ptrs(tensors):
+        return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def _device_guard(self, device):
+        return torch.cuda.device(device) if not self.host_memory else _NullCtx()
+
+    # ------------------------------------------------------------------ network
+    def forward(self, n_layers, ci, noisy, params, running, nbt, training, with_backward):
+        """Returns (enhanced, workspace).  Keep `workspace` alive until backward has been enqueued."""
+        if noisy.dim() != 3 or noisy.shape[1] != 1:
+            raise WunetError(f"input must be [batch, 1, samples], got {tuple(noisy.shape)}")
+        self._require(noisy, "input")
+        for k, p in enumerate(params):
+            self._require(p, f"param[{k}]")
+            if p.device != noisy.device:
+                raise WunetError("parameters and input live on different devices")
+        for t in list(running) + list(nbt):
+            self._require(t, "buffer")
+        B, _, T = noisy.shape
+        h = self._ctx_for(n_layers, ci, B, T)
+        nbytes = self.lib.wunet_workspace_bytes(h, 1 if with_backward else 0)
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=noisy.device)
+        out = torch.empty_like(noisy)
+        with self._device_guard(noisy.device):
+            self._check(self.lib.wunet_forward(h, noisy.data_ptr(), self._ptrs(params), self._ptrs(running),
+                                               self._ptrs(nbt), 1 if training else 0, ws.data_ptr(),
+                                               out.data_ptr(), self._stream(noisy.device)))
+        return out, ws
+
+    def backward(self, n_layers, ci, noisy, params, enhanced, grad_enhanced, ws, grads, layer_range=None):
+        B, _, T = noisy.shape
+        h = self._ctx_for(n_layers, ci, B, T)
+        self._require(grad_enhanced, "grad_output")
+        nl = 2 * n_layers + 1
+        lb, le = layer_range if layer_range is not None else (0, nl)
+        with self._device_guard(noisy.device):
+            self._check(self.lib.wunet_backward_range(h, noisy.data_ptr(), self._ptrs(params), enhanced.data_ptr(),
+                                                      grad_enhanced.data_ptr(), ws.data_ptr(), self._ptrs(grads),
+                                                      lb, le, self._stream(noisy.device)))
+
+    def layer_output(self, n_layers, ci, batch, length, ws, layer):
+        """Raw conv output (pre-BatchNorm) of conv layer `layer` as a view into a workspace (tests/profiling)."""
+        h = self._ctx_for(n_layers, ci, batch, length)
+        off, ch, ln = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
+        self._check(self.lib.wunet_layer_info(h, layer, ctypes.byref(off), ctypes.byref(ch), ctypes.byref(ln)))
+        return ws[off.value: off.value + batch * ch.value * ln.value].view(batch, ch.value, ln.value)
+
+    # ------------------------------------------------------------------ losses
+    def loss_forward(self, kind, clean, enhanced):
+        self._require(clean, "clean")
+        self._require(enhanced, "enhanced")
+        if clean.shape != enhanced.shape:
+            raise WunetError(f"loss: shape mismatch {tuple(clean.shape)} vs {tuple(enhanced.shape)}")
+        out = torch.empty((), dtype=torch.float32, device=enhanced.device)
+        scratch = torch.empty(self.lib.wunet_loss_scratch_bytes() // 8, dtype=torch.float64, device=enhanced.device)
+        with self._device_guard(enhanced.device):
+            self._check(self.lib.wunet_loss_forward(LOSS_KINDS[kind], clean.data_ptr(), enhanced.data_ptr(),
+                                                    enhanced.numel(), out.data_ptr(), scratch.data_ptr(),
+                                                    self._stream(enhanced.device)))
+        return out
+
+    def loss_backward(self, kind, clean, enhanced, grad_loss):
+        g = torch.empty_like(enhanced)
+        gl = grad_loss.to(torch.float32).contiguous()
+        with self._device_guard(enhanced.device):
+            self._check(self.lib.wunet_loss_backward(LOSS_KINDS[kind], clean.data_ptr(), enhanced.data_ptr(),
+                                                     gl.data_ptr(), enhanced.numel(), g.data_ptr(),
+                                                     self._stream(enhanced.device)))
+        return g
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_DEFAULT = None
+_DEFAULT_LOCK = threading.Lock()
+
+
+def default_engine():
+    global _DEFAULT
+    with _DEFAULT_LOCK:
+        if _DEFAULT is None:
+            _DEFAULT = Engine()
+    return _DEFAULT

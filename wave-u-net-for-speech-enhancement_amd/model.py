@@ -1,0 +1,120 @@
+"""Drop-in replacement of the reference model plugin.
+
+Select it from the reference's config exactly like any other plugin (util/utils.py:55-72):
+
+    "model": {"module": "wave-u-net-for-speech-enhancement_amd.model", "main": "Model", "args": {}}
+
+`Model(n_layers=12, channels_interval=24)` mirrors /root/reference/model/unet_basic.py:32-100:
+same constructor, `forward(input[B,1,T]) -> [B,1,T]`, same 177 state_dict entries
+(`encoder.{i}.main.0.weight`, `encoder.{i}.main.1.running_mean`, `middle.0.*`, `decoder.{i}.main.*`,
+`out.0.*`), same default initialisation under the same seed (the parameter containers are created in
+the reference's order), `.train()/.eval()` switching BatchNorm behaviour, `.to(device)/.cpu()`.
+The arithmetic is not torch's: forward and backward run the hand-written gfx950 kernels behind the
+C ABI of include/wunet_hip.h.  There is no CPU fallback: calling the module on a CPU tensor raises.
+"""
+import torch
+import torch.nn as nn
+
+from .engine import default_engine
+from .plan import conv_layer_shapes
+
+
+def _conv_bn(c_in, c_out, taps):
+    # parameter containers only (their forward is never called): keys main.0.* / main.1.*
+    return nn.Sequential(nn.Conv1d(c_in, c_out, kernel_size=taps, stride=1, padding=taps // 2),
+                         nn.BatchNorm1d(c_out))
+
+
+class _Level(nn.Module):
+    """Holds `main.0` (conv) and `main.1` (batch norm) like the reference's Down/UpSamplingLayer."""
+
+    def __init__(self, c_in, c_out, taps):
+        super().__init__()
+        self.main = _conv_bn(c_in, c_out, taps)
+
+
+class _WaveUNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, owner, need_grad, noisy, *params):
+        engine = owner._engine()
+        params = [p.detach() for p in params]
+        running, nbt = owner._wunet_buffers()
+        training = owner.training
+        out, ws = engine.forward(owner.n_layers, owner.channels_interval, noisy.detach(), params, running, nbt,
+                                 training, with_backward=need_grad and training)
+        ctx.owner = owner
+        ctx.training = training
+        ctx.ws = ws if need_grad else None
+        ctx.save_for_backward(noisy, out, *params)
+        if noisy.requires_grad:
+            raise NotImplementedError("gradient w.r.t. the waveform input is not part of the reference hot path "
+                                      "(encoder[0] needs no data gradient); detach the input")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if not ctx.training:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not implemented by the HIP path "
+                                      "(the reference only back-propagates in training mode, trainer/trainer.py:34-38)")
+        owner = ctx.owner
+        noisy, out, *params = ctx.saved_tensors
+        engine = owner._engine()
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=noisy.device)
+        grads, off = [], 0
+        for p in params:
+            grads.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        sync = owner.grad_sync
+        if sync is None:
+            engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out.contiguous(),
+                            ctx.ws, grads)
+        else:
+            sync.run(engine, owner, noisy, params, out, grad_out.contiguous(), ctx.ws, grads, flat)
+        owner.last_flat_grad = flat
+        ctx.ws = None
+        return (None, None, None, *grads)
+
+
+class Model(nn.Module):
+    def __init__(self, n_layers=12, channels_interval=24):
+        super().__init__()
+        self.n_layers = n_layers
+        self.channels_interval = channels_interval
+        shapes = conv_layer_shapes(n_layers, channels_interval)
+        enc, mid, dec = shapes[:n_layers], shapes[n_layers], shapes[n_layers + 1:]
+        # construction order == reference order, so default init consumes the RNG identically
+        self.encoder = nn.ModuleList([_Level(*s) for s in enc])
+        self.middle = _conv_bn(*mid)
+        self.decoder = nn.ModuleList([_Level(*s) for s in dec])
+        self.out = nn.Sequential(nn.Conv1d(1 + channels_interval, 1, kernel_size=1, stride=1))
+        self.grad_sync = None          # set by parallel.GradSync for RCCL data parallelism
+        self.last_flat_grad = None     # flat fp32 gradient buffer of the latest backward
+        self._engine_override = None
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _engine(self):
+        return self._engine_override if self._engine_override is not None else default_engine()
+
+    def _blocks(self):
+        return [lv.main for lv in self.encoder] + [self.middle] + [lv.main for lv in self.decoder]
+
+    def _wunet_params(self):
+        ps = []
+        for blk in self._blocks():
+            ps += [blk[0].weight, blk[0].bias, blk[1].weight, blk[1].bias]
+        ps += [self.out[0].weight, self.out[0].bias]
+        return ps
+
+    def _wunet_buffers(self):
+        running, nbt = [], []
+        for blk in self._blocks():
+            running += [blk[1].running_mean, blk[1].running_var]
+            nbt.append(blk[1].num_batches_tracked)
+        return running, nbt
+
+    def forward(self, input):
+        if input.dtype != torch.float32:
+            raise TypeError(f"Model expects float32 waveforms, got {input.dtype}")
+        params = self._wunet_params()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _WaveUNetFn.apply(self, need_grad, input.contiguous(), *params)
