@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the Wave-U-Net hot path on MI355X (contract: see the round brief).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one training step of the reference's hot loop (trainer/trainer.py:34-38) on one batch of
+synthetic frames already resident in HBM: zero_grad, forward, smooth-L1 loss, backward (with the
+bucketed RCCL gradient all-reduce when N>1), Adam step.  Metric: 16384-sample frames per second,
+whole job.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+import torch
+import torch.distributed as dist
+
+PKG = "wave-u-net-for-speech-enhancement_amd"
+N_LAYERS, CI, FRAME = 12, 24, 16384
+FWD_FLOP_PER_FRAME = 4.885e9
+FWDBWD_FLOP_PER_FRAME = 14.643e9
+FWDBWD_BYTES_PER_FRAME = 99.54e6
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak == fp32 vector peak
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_batch(batch, device, seed):
+    g = torch.Generator().manual_seed(seed)
+    clean = torch.rand(batch, 1, FRAME, generator=g) * 2 - 1
+    noisy = clean + 0.1 * torch.randn(batch, 1, FRAME, generator=g)
+    return noisy.to(device), clean.to(device)
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The reference's CPU path (same ATen ops via oracle/torch_port.py, which is bit-identical to the
+    imported reference) on the host cores: B=4 training steps (BASELINE.json configs[0])."""
+    from oracle import plan, torch_port
+    torch.manual_seed(0)
+    sd = torch_port.state_to_torch(plan.golden_state(N_LAYERS, CI, 0), requires_grad=True)
+    params = [v for k, v in sd.items() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
+    noisy, clean = synthetic_batch(4, "cpu", 0)
+    times = []
+    t_start = time.perf_counter()
+    for it in range(12):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        out = torch_port.forward(sd, noisy, N_LAYERS, CI, True)
+        loss = torch_port.loss_value("smooth_l1", clean, out)
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+        if it >= 2 and time.perf_counter() - t_start > seconds_budget:
+            break
+    steady = sorted(times[1:])
+    med = steady[len(steady) // 2]
+    return {"value": 4.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"batch=4 x {FRAME}-sample frames, fwd+smooth_l1+bwd+Adam, median of {len(steady)} steps "
+                      f"(torch {torch.__version__} CPU ATen kernels = the reference's CUDA_VISIBLE_DEVICES=-1 path)",
+            "cpu_count": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU (weak scaling)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    pkg = importlib.import_module(PKG)
+    parallel = importlib.import_module(PKG + ".parallel")
+    engine_mod = importlib.import_module(PKG + ".engine")
+
+    torch.manual_seed(0)                         # same init on every rank (reference train.py:12)
+    model = pkg.Model(n_layers=N_LAYERS, channels_interval=CI).to(device).train()
+    crit = pkg.smooth_l1_loss()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))     # reference train.py:31-35
+    if world > 1:
+        model.grad_sync = parallel.GradSync(n_buckets=4)
+    noisy, clean = synthetic_batch(args.batch, device, seed=rank)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(noisy)
+        loss = crit(clean, out)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    frames_per_s = args.batch * world * args.steps / elapsed
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # per-kernel durations: HIP events recorded by the library on the launch stream around every MFMA
+        # kernel, over a second pass of the same steps (events perturb the launch stream slightly, so the
+        # headline value above is taken without them)
+        lib = engine_mod.default_engine().lib
+        lib.wunet_profile_enable(1)
+        nprof = max(1, min(args.steps, 5))
+        for _ in range(nprof):
+            step()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.wunet_profile_collect(buf, len(buf))
+        lib.wunet_profile_enable(0)
+        rows = []
+        for line in buf.value.decode().strip().splitlines():
+            name, n, ms, fl, by = line.split("\t")
+            rows.append({"kernel": name, "launches": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
+        rows.sort(key=lambda r: -r["ms"])
+        if rows:
+            top = rows[0]
+            avg_ms = top["ms"] / top["launches"]
+            achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+            mfma_ms = sum(r["ms"] for r in rows) / nprof
+            roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
+                        "mfma_kernels_ms_per_step": mfma_ms,
+                        "all_mfma_kernels_achieved": sum(r["flops"] for r in rows) / nprof / (mfma_ms * 1e-3) / 1e12,
+                        "top5": [{"kernel": r["kernel"], "ms_per_step": r["ms"] / nprof,
+                                  "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12} for r in rows[:5]]}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        per_gpu_fps = frames_per_s / world
+        result = {
+            "metric": "16384-sample frames/sec fwd+bwd, 12-level Wave-U-Net",
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"unet_basic 12-level, {FRAME}-sample frames, batch={args.batch} per GPU, fp32, "
+                                   "training-mode forward + smooth_l1 + backward + Adam step "
+                                   "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",
+                       "global_batch": args.batch * world, "frame": FRAME,
+                       "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
+            "whole_step_tflops_per_gpu": per_gpu_fps * FWDBWD_FLOP_PER_FRAME / 1e12,
+            "whole_step_frac_of_fp32_peak": per_gpu_fps * FWDBWD_FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "whole_step_algorithmic_hbm_frac": per_gpu_fps * FWDBWD_BYTES_PER_FRAME / 1e9 / PEAK_HBM_GBS,
+            "final_loss": final_loss,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

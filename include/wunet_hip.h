@@ -83,6 +83,13 @@ int wunet_loss_backward(int kind, const float* clean, const float* enhanced, con
 int wunet_layer_info(const wunet_ctx* ctx, int layer, size_t* z_offset_floats, int* channels, int* length);
 int wunet_num_conv_layers(const wunet_ctx* ctx);
 
+/* Optional per-launch timing of the MFMA kernels with HIP events recorded on the launch stream
+ * (bench.py's roofline leg; no reference counterpart).  collect() synchronises the device, writes
+ * "kernel name\tlaunches\ttotal_ms\ttotal_algorithmic_flops\ttotal_algorithmic_bytes\n" per kernel
+ * into buf and clears the records. */
+int wunet_profile_enable(int on);
+long long wunet_profile_collect(char* buf, size_t cap);
+
 /* Single-op entry points (parity tests of the MFMA kernels against F.conv1d semantics,
  * nn.Conv1d stride 1, padding K/2, K in {5, 15}).  They allocate scratch and synchronise. */
 int wunet_op_conv1d(const float* x, const float* w, const float* bias, float* z,

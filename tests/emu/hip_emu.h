@@ -87,6 +87,7 @@ inline float wunet_shfl_xor(float v, int mask)
 // ---- minimal host runtime
 typedef void* hipStream_t;
 typedef int hipError_t;
+typedef void* hipEvent_t;
 #define hipSuccess 0
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 2; }
 inline hipError_t hipFree(void* p) { std::free(p); return 0; }

@@ -1,0 +1,234 @@
+"""-m gpu: the HIP path (through the C ABI and the nn.Module) against the oracle, the golden
+fixtures generated from the imported reference, and size-independent properties at BASELINE.json's
+full size.  Tolerance: north_star's 1e-4 absolute in fp32 (outputs, loss, gradients); tighter
+relative bars where the fp32 noise floor allows."""
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import PKG_NAME, golden
+from golden.make_digest import digest
+from oracle import c_oracle, plan, torch_port
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def engine():
+    return importlib.import_module(PKG_NAME + ".engine").default_engine()
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_native_library_is_the_hip_one(engine):
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    assert engine.lib is lib_mod.load_hip() and not engine.host_memory
+    assert "libwunet_hip.so" in open("/proc/self/maps").read()
+
+
+def test_cpu_tensor_is_rejected(pkg):
+    m = pkg.Model(n_layers=2, channels_interval=4)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 1, 64))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,L,K", [
+    (2, 8, 24, 64, 15), (1, 1, 24, 1024, 15), (3, 5, 40, 32, 5), (2, 30, 12, 8, 5), (2, 12, 100, 4, 15),
+    (4, 24, 48, 8192, 15),       # BASELINE encoder[1] geometry, N_REP=4 path
+    (8, 72, 24, 16384, 5),       # decoder[11] geometry
+    (4, 288, 288, 4, 15),        # middle geometry
+    (2, 576, 288, 8, 5),         # decoder[0] geometry
+])
+def test_conv_ops_vs_oracle(engine, dev, B, Cin, Cout, L, K):
+    rng = np.random.default_rng(B * 1000 + Cin)
+    x = rng.standard_normal((B, Cin, L)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, K)) / np.sqrt(Cin * K)).astype(np.float32)
+    b = rng.standard_normal((Cout,)).astype(np.float32)
+    gz = rng.standard_normal((B, Cout, L)).astype(np.float32)
+    xd, wd, bd, gd = _t(x, dev), _t(w, dev), _t(b, dev), _t(gz, dev)
+    z = torch.full((B, Cout, L), float("nan"), device=dev)
+    dx = torch.full((B, Cin, L), float("nan"), device=dev)
+    dw = torch.full((Cout, Cin, K), float("nan"), device=dev)
+    lib = engine.lib
+    assert lib.wunet_op_conv1d(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), z.data_ptr(), B, Cin, Cout, L, K, None) == 0
+    assert lib.wunet_op_conv1d_dgrad(gd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, Cin, Cout, L, K, None) == 0
+    assert lib.wunet_op_conv1d_wgrad(gd.data_ptr(), xd.data_ptr(), dw.data_ptr(), B, Cin, Cout, L, K, None) == 0
+    torch.cuda.synchronize()
+    zr = c_oracle.conv1d_fwd(x, w, b)
+    dxr, dwr, _ = c_oracle.conv1d_bwd(gz, x, w)
+    assert np.abs(z.cpu().numpy() - zr).max() < 1e-5 * max(1.0, np.abs(zr).max())
+    assert np.abs(dx.cpu().numpy() - dxr).max() < 1e-5 * max(1.0, np.abs(dxr).max())
+    # wgrad reduces over B*L positions in fp32 MFMA chains + split-K: relative to its own scale
+    assert np.abs(dw.cpu().numpy() - dwr).max() < 2e-5 * max(1.0, np.abs(dwr).max())
+
+
+@pytest.mark.parametrize("kind", ["mse", "l1", "smooth_l1"])
+def test_loss_vs_torch(pkg, dev, kind):
+    g = torch.Generator().manual_seed(1)
+    clean = (torch.rand(3, 1, 4096, generator=g) * 4 - 2).to(dev)
+    enh = (torch.rand(3, 1, 4096, generator=g) * 4 - 2).to(dev).requires_grad_(True)
+    crit = {"mse": pkg.mse_loss, "l1": pkg.l1_loss, "smooth_l1": pkg.smooth_l1_loss}[kind]()
+    lv = crit(clean, enh)
+    lv.backward()
+    e2 = enh.detach().clone().requires_grad_(True)
+    ref = torch_port.loss_value(kind, clean, e2)
+    ref.backward()
+    assert abs(lv.item() - ref.item()) < 1e-6
+    assert (enh.grad - e2.grad).abs().max().item() < 1e-9
+
+
+def _run_model(pkg, dev, n, ci, noisy, clean, loss, training=True):
+    sd = plan.golden_state(n, ci, 0)
+    m = pkg.Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.to(dev)
+    m.train(training)
+    crit = {"mse": pkg.mse_loss, "l1": pkg.l1_loss, "smooth_l1": pkg.smooth_l1_loss}[loss]()
+    if not training:
+        with torch.no_grad():
+            return m, m(_t(noisy, dev)), None
+    out = m(_t(noisy, dev))
+    lv = crit(_t(clean, dev), out)
+    lv.backward()
+    torch.cuda.synchronize()
+    return m, out, lv
+
+
+@pytest.mark.parametrize("name", ["tiny_mse", "small_l1", "small_smoothl1"])
+def test_golden_small_cases(pkg, dev, name):
+    """Every tensor the imported reference produced for the small cases (tests/golden/make_golden.py)."""
+    fx = golden(name)
+    n, ci, B, T = (int(v) for v in fx["meta"])
+    noisy, clean = plan.golden_batch(B, T, 0)
+    m, out, lv = _run_model(pkg, dev, n, ci, noisy, clean, str(fx["loss_kind"]))
+    assert np.abs(out.detach().cpu().numpy() - fx["out_train"]).max() < TOL
+    assert abs(lv.item() - float(fx["loss"])) < 1e-5
+    for k, p in m.named_parameters():
+        ref = fx["grad/" + k]
+        err = np.abs(p.grad.cpu().numpy() - ref).max()
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            assert np.all(p.grad.cpu().numpy() == 0.0) and np.abs(ref).max() < 1e-6   # true gradient is 0
+        else:
+            assert err < TOL and err < 5e-4 * max(np.abs(ref).max(), 1e-6) + 1e-7, (k, err)
+    post = m.state_dict()
+    for k in plan.buffer_names(n, ci):
+        assert np.abs(post[k].cpu().numpy().astype(np.float64) - fx["buf/" + k]).max() < 1e-5, k
+    m2, out_eval, _ = _run_model(pkg, dev, n, ci, noisy, clean, "mse", training=False)
+    assert np.abs(out_eval.cpu().numpy() - fx["out_eval"]).max() < TOL
+
+
+def test_golden_full_12_level(pkg, dev):
+    """12-level / 16384 samples / B=2 against the reference fixture: output, loss, gradient and
+    running-stat digests."""
+    fx = golden("full12_mse")
+    n, ci, B, T = (int(v) for v in fx["meta"])
+    noisy, clean = plan.golden_batch(B, T, 0)
+    m, out, lv = _run_model(pkg, dev, n, ci, noisy, clean, "mse")
+    assert np.abs(out.detach().cpu().numpy() - fx["out_train"]).max() < TOL
+    assert abs(lv.item() - float(fx["loss"])) < 1e-5
+    for i, (k, p) in enumerate(m.named_parameters()):
+        ref = fx["grad_digest"][i]
+        g = p.grad.cpu().numpy()
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            assert np.all(g == 0.0)
+            continue
+        got = digest(g)
+        rms = ref[0] / np.sqrt(g.size)
+        assert abs(got[0] - ref[0]) < 5e-3 * ref[0] + 1e-7, (k, got[0], ref[0])
+        err = np.abs(got[2:] - ref[2:]).max()
+        assert err < TOL and err < 0.05 * rms + 1e-7, (k, err, rms)
+    post = m.state_dict()
+    for i, k in enumerate(plan.buffer_names(n, ci)):
+        ref = fx["buf_digest"][i]
+        got = digest(post[k].cpu().numpy())
+        assert abs(got[0] - ref[0]) < 1e-4 * abs(ref[0]) + 1e-6, k
+    m2, out_eval, _ = _run_model(pkg, dev, n, ci, noisy, clean, "mse", training=False)
+    assert np.abs(out_eval.cpu().numpy() - fx["out_eval"]).max() < TOL
+
+
+def test_layer_activations_vs_oracle(pkg, engine, dev):
+    """Per-layer raw conv outputs (all 2n+1 layers) against the oracle: localises any mismatch."""
+    n, ci, B, T = 5, 8, 2, 512
+    sd = plan.golden_state(n, ci, 0)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, True, "mse", want_acts=True)
+    m = pkg.Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.to(dev).train()
+    running, nbt = m._wunet_buffers()
+    out, ws = engine.forward(n, ci, _t(noisy, dev), [p.detach() for p in m._wunet_params()], running, nbt, True, False)
+    torch.cuda.synchronize()
+    for i in range(2 * n + 1):
+        z = engine.layer_output(n, ci, B, T, ws, i).cpu().numpy()
+        assert np.abs(z - ref["acts"][i]).max() < 2e-5 * max(1.0, np.abs(ref["acts"][i]).max()), i
+
+
+def test_full_size_properties(pkg, dev):
+    """BASELINE.json configs[1]/[2] size (12-level, batch 64 x 16384).
+    (a) eval mode: frames are independent -> the batch-64 output equals the outputs of 8-frame slices;
+    (b) train mode: forward / loss / gradients against the reference's own ATen CPU path
+        (oracle/torch_port.py, bit-identical to the imported reference, see tests/golden/make_golden.py)."""
+    n, ci, B, T = 12, 24, 64, 16384
+    noisy, clean = plan.golden_batch(B, T, 3)
+    m, out_eval, _ = _run_model(pkg, dev, n, ci, noisy, clean, "mse", training=False)
+    with torch.no_grad():
+        parts = [m(_t(noisy[i:i + 8], dev)) for i in range(0, B, 8)]
+    sliced = torch.cat(parts, 0)
+    assert (sliced - out_eval).abs().max().item() <= 1e-6
+
+    m, out, lv = _run_model(pkg, dev, n, ci, noisy, clean, "smooth_l1")
+    tsd = torch_port.state_to_torch(plan.golden_state(n, ci, 0), requires_grad=True)
+    o2 = torch_port.forward(tsd, torch.from_numpy(noisy), n, ci, True)
+    l2 = torch_port.loss_value("smooth_l1", torch.from_numpy(clean), o2)
+    l2.backward()
+    assert (out.detach().cpu() - o2.detach()).abs().max().item() < TOL
+    assert abs(lv.item() - l2.item()) < 1e-5
+    for k, p in m.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            continue
+        ref = tsd[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item()
+        rel = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        assert err < TOL and rel < 2e-2, (k, err, rel)
+    post = m.state_dict()
+    for k in plan.buffer_names(n, ci):
+        if "num_batches" in k:
+            assert int(post[k]) == int(tsd[k])
+        else:
+            assert (post[k].cpu() - tsd[k]).abs().max().item() < 1e-5, k
+
+
+def test_backward_range_equals_full(pkg, engine, dev):
+    """wunet_backward_range in buckets (the RCCL-overlap path) == one wunet_backward call, bit for bit."""
+    n, ci, B, T = 4, 8, 2, 256
+    sd = plan.golden_state(n, ci, 0)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    m = pkg.Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.to(dev).train()
+    params = [p.detach() for p in m._wunet_params()]
+    running, nbt = m._wunet_buffers()
+    x = _t(noisy, dev)
+    out, ws = engine.forward(n, ci, x, params, running, nbt, True, True)
+    gout = torch.randn_like(out)
+    g1 = [torch.empty_like(p) for p in params]
+    g2 = [torch.empty_like(p) for p in params]
+    engine.backward(n, ci, x, params, out, gout, ws, g1)
+    nl = 2 * n + 1
+    for lb, le in [(6, nl), (3, 6), (0, 3)]:
+        engine.backward(n, ci, x, params, out, gout, ws, g2, layer_range=(lb, le))
+    torch.cuda.synchronize()
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)

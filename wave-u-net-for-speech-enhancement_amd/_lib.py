@@ -13,7 +13,7 @@ EXPORTS = [
     "wunet_last_error", "wunet_create", "wunet_destroy", "wunet_workspace_bytes", "wunet_forward",
     "wunet_backward", "wunet_backward_range", "wunet_loss_scratch_bytes", "wunet_loss_forward",
     "wunet_loss_backward", "wunet_layer_info", "wunet_num_conv_layers", "wunet_op_conv1d",
-    "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad",
+    "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
 ]
 
 _vp = ctypes.c_void_p
@@ -43,6 +43,9 @@ def declare(lib):
         getattr(lib, name).argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_op_conv1d_dgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_op_conv1d_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.wunet_profile_enable.argtypes = [_i]
+    lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
+    lib.wunet_profile_collect.restype = ctypes.c_longlong
     return lib
 
 

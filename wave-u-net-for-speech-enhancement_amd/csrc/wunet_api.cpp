@@ -3,6 +3,7 @@
 // path (the caller owns the workspace), nothing synchronises the stream.
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,32 @@ int fail(int code, const char* fmt, ...)
         hipError_t e_ = hipGetLastError();                                                     \
         if (e_ != hipSuccess) return fail(WUNET_E_RUNTIME, "%s:%d HIP error: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
     } while (0)
+
+// ---- optional per-launch profiler (HIP events on the launch stream), used by bench.py's roofline leg
+struct ProfRec { std::string name; double flops; double bytes; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+
+#ifdef WUNET_EMU
+inline void prof_begin(hipStream_t, const char*, double, double) {}
+inline void prof_end(hipStream_t) {}
+#else
+inline void prof_begin(hipStream_t st, const char* name, double flops, double bytes)
+{
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    hipEventCreate(&r.e0);
+    hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, st);
+    g_prof.push_back(r);
+}
+inline void prof_end(hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEventRecord(g_prof.back().e1, st);
+}
+#endif
 
 int ilog2(long long v) { int r = 0; while ((1LL << r) < v) ++r; return r; }
 bool is_pow2(long long v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -135,6 +162,11 @@ SrcDesc gz_src(const float* g, const float* z, const float* k1, const float* k2,
 int launch_conv_any(int taps, int mode, const ConvArgs& a, int mrep, int nrep, dim3 grid, hipStream_t st)
 {
     const int kc = kc_of(taps);
+    char pname[96];
+    snprintf(pname, sizeof pname, "conv_mfma_kernel<%d, %d, %d, %d>", taps, mode, mrep, nrep);
+    // algorithmic work: 2*B*L*Cout*Cin*taps flops; the virtual input read once + the output written once
+    const double posn = (double)a.B * a.src.L;
+    prof_begin(st, pname, 2.0 * posn * a.Cout * a.src.C * taps, 4.0 * posn * (a.Cout + a.src.C));
     const size_t smem = ((size_t)kc * a.geo.rowp + (size_t)mrep * kc * taps * 16) * sizeof(float);
     int rc = -1;
     if (taps == 15 && mode == SRC_RAW) rc = wunet_launch_conv_15_0(a, mrep, nrep, grid, smem, st);
@@ -143,6 +175,7 @@ int launch_conv_any(int taps, int mode, const ConvArgs& a, int mrep, int nrep, d
     else if (taps == 15 && mode == SRC_GZ) rc = wunet_launch_conv_15_3(a, mrep, nrep, grid, smem, st);
     else if (taps == 5 && mode == SRC_GZ) rc = wunet_launch_conv_5_3(a, mrep, nrep, grid, smem, st);
     else if (taps == 5 && mode == SRC_RAW) rc = wunet_launch_conv_5_0(a, mrep, nrep, grid, smem, st);
+    prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv kernel for taps=%d mode=%d mrep=%d nrep=%d", taps, mode, mrep, nrep);
     return 0;
 }
@@ -152,10 +185,15 @@ int launch_wgrad_any(int taps, int mode, const WgradArgs& a, int mrep, dim3 grid
     const int cib = 24;
     const size_t smem = ((size_t)mrep * 16 * 66 + (size_t)cib * a.geo.rowp) * sizeof(float);
     int rc = -1;
+    char pname[96];
+    snprintf(pname, sizeof pname, "wgrad_mfma_kernel<%d, %d, %d, %d>", taps, mode, mrep, taps == 15 ? 6 : 2);
+    const double posn = (double)a.B * a.x.L;
+    prof_begin(st, pname, 2.0 * posn * a.Cout * a.Cin * taps, 4.0 * posn * (2.0 * a.Cout + a.Cin));
     if (taps == 15 && mode == SRC_RAW) rc = wunet_launch_wgrad_15_0(a, mrep, grid, smem, st);
     else if (taps == 15 && mode == SRC_DECIM) rc = wunet_launch_wgrad_15_1(a, mrep, grid, smem, st);
     else if (taps == 5 && mode == SRC_UPCAT) rc = wunet_launch_wgrad_5_2(a, mrep, grid, smem, st);
     else if (taps == 5 && mode == SRC_RAW) rc = wunet_launch_wgrad_5_0(a, mrep, grid, smem, st);
+    prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no wgrad kernel for taps=%d mode=%d mrep=%d", taps, mode, mrep);
     return 0;
 }
@@ -492,6 +530,49 @@ int wunet_loss_backward(int kind, const float* clean, const float* enhanced, con
     WUNET_LAUNCH(loss_bwd_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, kind, clean, enhanced, grad_loss, n, grad_enhanced);
     WUNET_CHECK_LAUNCH();
     return WUNET_OK;
+}
+
+// ---------------------------------------------------------------------------- profiler
+int wunet_profile_enable(int on)
+{
+    g_prof_on = on != 0;
+    return WUNET_OK;
+}
+
+// Writes one line per kernel name: "name\tlaunches\ttotal_ms\ttotal_flops\ttotal_bytes\n"; clears the records.
+// Synchronises the device.  Returns the number of bytes written (<= cap-1) or a negative code.
+long long wunet_profile_collect(char* buf, size_t cap)
+{
+#ifdef WUNET_EMU
+    if (cap) buf[0] = 0;
+    return 0;
+#else
+    if (hipDeviceSynchronize() != hipSuccess) return fail(WUNET_E_RUNTIME, "hipDeviceSynchronize");
+    struct Agg { std::string name; long n; double ms, fl, by; };
+    std::vector<Agg> agg;
+    for (ProfRec& r : g_prof) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+        size_t k = 0;
+        for (; k < agg.size(); ++k) if (agg[k].name == r.name) break;
+        if (k == agg.size()) agg.push_back(Agg{r.name, 0, 0.0, 0.0, 0.0});
+        agg[k].n += 1; agg[k].ms += ms; agg[k].fl += r.flops; agg[k].by += r.bytes;
+    }
+    g_prof.clear();
+    std::string out;
+    char line[256];
+    for (const Agg& a : agg) {
+        snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\t%.6e\n", a.name.c_str(), a.n, a.ms, a.fl, a.by);
+        out += line;
+    }
+    if (cap == 0) return 0;
+    const size_t nb = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), nb);
+    buf[nb] = 0;
+    return (long long)nb;
+#endif
 }
 
 // ---------------------------------------------------------------------------- single-op entry points

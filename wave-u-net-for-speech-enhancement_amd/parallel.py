@@ -1,0 +1,69 @@
+"""Data parallelism for the hot path: one process per GPU, RCCL all-reduce of the flat gradient
+buffer over xGMI, bucketed in backward-completion order and overlapped with the remaining backward
+kernels.  Replaces the reference's single-process torch.nn.DataParallel wrap
+(/root/reference/trainer/base_trainer.py:26-27).
+
+Semantics kept from DataParallel: BatchNorm statistics stay local to each replica (no SyncBN),
+running statistics are not reduced, and with equal shards the summed gradient of the global-mean
+loss equals the average of the per-shard mean-loss gradients - so buckets are summed and scaled by
+1/world_size.  Every rank then takes the identical optimiser step; no parameter broadcast follows.
+"""
+import torch
+import torch.distributed as dist
+
+
+def bucket_ranges(param_numels, n_conv_layers, n_buckets):
+    """Split conv layers [0, NL) into <= n_buckets contiguous ranges, walked in backward order
+    (last layer first), balanced by gradient bytes.  Layer i owns params 4i..4i+3; the output head's
+    two tensors belong to the last layer's bucket.  Returns [(layer_begin, layer_end, flat_begin, flat_end)]
+    in execution order."""
+    nl = n_conv_layers
+    per_layer = [sum(param_numels[4 * i:4 * i + 4]) for i in range(nl)]
+    per_layer[nl - 1] += sum(param_numels[4 * nl:4 * nl + 2])
+    offsets = [0]
+    for v in param_numels:
+        offsets.append(offsets[-1] + v)
+    total = sum(per_layer)
+    target = total / max(1, n_buckets)
+    ranges, end, acc = [], nl, 0
+    for i in range(nl - 1, -1, -1):
+        acc += per_layer[i]
+        remaining_buckets = n_buckets - len(ranges) - 1
+        if (acc >= target and remaining_buckets > 0 and i > 0) or i == 0:
+            flat_end = offsets[4 * end] if end < nl else offsets[-1]
+            ranges.append((i, end, offsets[4 * i], flat_end))
+            end, acc = i, 0
+    return ranges
+
+
+class GradSync:
+    """Attach with `model.grad_sync = GradSync(...)`; the model's backward then runs the layer
+    ranges through wunet_backward_range and enqueues one asynchronous all-reduce per finished bucket."""
+
+    def __init__(self, process_group=None, n_buckets=4):
+        self.group = process_group
+        self.n_buckets = n_buckets
+        self._ranges = {}
+
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def ranges_for(self, params, n_conv_layers):
+        key = (n_conv_layers, tuple(p.numel() for p in params))
+        if key not in self._ranges:
+            self._ranges[key] = bucket_ranges([p.numel() for p in params], n_conv_layers, self.n_buckets)
+        return self._ranges[key]
+
+    def run(self, engine, owner, noisy, params, out, grad_out, ws, grads, flat):
+        nl = 2 * owner.n_layers + 1
+        world = self.world_size()
+        pending = []
+        for lb, le, fb, fe in self.ranges_for(params, nl):
+            engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out, ws, grads,
+                            layer_range=(lb, le))
+            if world > 1:
+                seg = flat[fb:fe]
+                pending.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
+        for work, seg in pending:
+            work.wait()                  # stream-level dependency on the RCCL stream, host does not block
+            seg.mul_(1.0 / world)
