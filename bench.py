@@ -50,24 +50,36 @@ def cpu_baseline(seconds_budget=20.0):
     params = [v for k, v in sd.items() if v.requires_grad]
     opt = torch.optim.Adam(params, lr=1e-3, betas=(0.9, 0.999))
     noisy, clean = synthetic_batch(4, "cpu", 0)
-    times = []
-    t_start = time.perf_counter()
-    for it in range(12):
+
+    def one_step():
         t0 = time.perf_counter()
         opt.zero_grad()
         out = torch_port.forward(sd, noisy, N_LAYERS, CI, True)
         loss = torch_port.loss_value("smooth_l1", clean, out)
         loss.backward()
         opt.step()
-        times.append(time.perf_counter() - t0)
-        if it >= 2 and time.perf_counter() - t_start > seconds_budget:
+        return time.perf_counter() - t0
+
+    # the host has far more cores than a batch-4 step can use: sweep the thread count, keep the best
+    ncpu = os.cpu_count() or 1
+    sweep = sorted({t for t in (8, 16, 32, 64, ncpu // 2) if 1 <= t <= ncpu})
+    best = None
+    t_start = time.perf_counter()
+    tried = {}
+    for nt in sweep:
+        torch.set_num_threads(nt)
+        one_step()
+        ts = sorted(one_step() for _ in range(3))
+        tried[nt] = 4.0 / ts[1]
+        if best is None or ts[1] < best[1]:
+            best = (nt, ts[1])
+        if time.perf_counter() - t_start > seconds_budget:
             break
-    steady = sorted(times[1:])
-    med = steady[len(steady) // 2]
-    return {"value": 4.0 / med, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"batch=4 x {FRAME}-sample frames, fwd+smooth_l1+bwd+Adam, median of {len(steady)} steps "
-                      f"(torch {torch.__version__} CPU ATen kernels = the reference's CUDA_VISIBLE_DEVICES=-1 path)",
-            "cpu_count": os.cpu_count()}
+    return {"value": 4.0 / best[1], "unit": "frames/s", "cores": best[0], "kind": "port",
+            "sample": f"batch=4 x {FRAME}-sample frames, fwd+smooth_l1+bwd+Adam, median of 3 steps at the best of "
+                      f"{list(tried)} threads (torch {torch.__version__} CPU ATen kernels = the reference's "
+                      "CUDA_VISIBLE_DEVICES=-1 path)",
+            "frames_per_s_by_threads": tried, "cpu_count": ncpu}
 
 
 def main():

@@ -31,9 +31,17 @@ __device__ __forceinline__ float wunet_lrelu(float v) { return v > 0.0f ? v : WU
 // ATen upsample_linear1d(align_corners=True) source coordinate, fp32 arithmetic on purpose
 // (reference model/unet_basic.py:93 -> ATen UpSample.h area_pixel_compute_source_index +
 // guard_index_and_lambda).  scale = (float)(Lin-1)/(Lout-1) is computed on the host the same way.
+// The multiply must round to fp32 before the subtraction: hipcc's default -ffp-contract=fast would fuse
+// `scale*j - i0` into one fma (an exact product), which is 4e-4 away from the reference end to end.
 __device__ __forceinline__ void wunet_up_coord(int j, int Lin, float scale, int& i0, int& i1, float& l0, float& l1)
 {
-    const float src = scale * (float)j;
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+    float src = scale * (float)j;
+#if !defined(WUNET_EMU)
+    asm volatile("" : "+v"(src));     // belt and braces: the rounded product is opaque to later fusion
+#endif
     int a = (int)floorf(src);
     a = a > Lin - 1 ? Lin - 1 : a;
     float lam = src - (float)a;
