@@ -50,10 +50,11 @@ size_t wunet_workspace_bytes(const wunet_ctx* ctx, int with_backward);
 /* Replaces Model.forward (model/unet_basic.py:77-100).
  * training != 0: BatchNorm uses batch statistics and updates running_mean/var (momentum 0.1,
  * unbiased variance) and num_batches_tracked in place; otherwise running statistics are used.
- * The workspace keeps the raw conv outputs and BN statistics for wunet_backward. */
+ * save_for_backward != 0 (needs a with_backward=1 workspace): additionally keeps what wunet_backward
+ * needs - the raw conv outputs, BN statistics and each conv's activated input. */
 int wunet_forward(wunet_ctx* ctx, const float* noisy, const float* const* params,
                   float* const* running, long long* const* num_batches_tracked, int training,
-                  void* workspace, float* enhanced, void* stream);
+                  int save_for_backward, void* workspace, float* enhanced, void* stream);
 
 /* Replaces autograd's backward of Model.forward (trainer/trainer.py:37 loss.backward()).
  * Must follow a training-mode wunet_forward on the same ctx/workspace/params/noisy.

@@ -24,6 +24,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct float4 { float x, y, z, w; };
+struct float2 { float x, y; };
 
 namespace emu {
 struct FiberState { dim3 tidx; int op_parity; };

@@ -30,7 +30,7 @@ def declare(lib):
     lib.wunet_destroy.restype = None
     lib.wunet_workspace_bytes.argtypes = [_vp, _i]
     lib.wunet_workspace_bytes.restype = _sz
-    lib.wunet_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]
+    lib.wunet_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]
     lib.wunet_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.wunet_backward_range.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
     lib.wunet_loss_scratch_bytes.restype = _sz

@@ -92,18 +92,21 @@ TileGeom make_geom(int L, int TN, int pad, int extra_cols, int row_mod)
 
 enum { LK_RAW = 0, LK_DECIM = 1, LK_UPCAT = 2 };
 
+struct WgradCfg { int mrep, nw, xit, wsplit, mblocks, nblocks, ksplit, cps, rows; };
+
 struct LayerPlan {
     int cin, cout, taps, L, logL, kind;
     int src0, src1;      // producer layers (src0 = -1: network input)
     int c0;              // UPCAT: channels from the upsampled branch
     // forward conv
-    int f_mrep, f_nrep, f_mblocks, f_cinp, f_mtiles_p, f_grid_x, f_rows;
+    int f_mrep, f_nrep, f_mblocks, f_cinp, f_mtiles_p, f_grid_x, f_rows, f_ksplit, f_kcps;
     size_t f_wpk;
     // data gradient (rows = cin, K-channels = cout)
-    int d_mrep, d_nrep, d_mblocks, d_cp, d_mtiles_p, d_grid_x;
+    int d_mrep, d_nrep, d_mblocks, d_cp, d_mtiles_p, d_grid_x, d_ksplit, d_kcps;
     size_t d_wpk;
     // weight gradient
-    int w_mrep, w_nw, w_mblocks, w_nblocks, w_ksplit, w_cps;
+    WgradCfg w;
+    size_t xin;          // materialised activated conv input [B][cin][L] (layers >= 1), float offset
     // pass A
     int a_split;
     // workspace (float offsets)
@@ -115,8 +118,8 @@ struct LayerPlan {
 struct wunet_ctx {
     int n, ci, B, T, NL;
     std::vector<LayerPlan> ly;
-    size_t stats_off, wpkf_off, fwd_floats;
-    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
+    size_t stats_off, wpkf_off, spart_off, fwd_floats;
+    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, gz_off, total_floats;
     int head_blocks;
 };
 
@@ -128,6 +131,22 @@ int conv_nrep(int B, int L, int mblocks)
 {
     const long long pos = (long long)B * L;
     return (L >= 256 && (pos / 256) * mblocks >= 256) ? 4 : 1;
+}
+
+// split-K over input-channel chunks when a layer has too few (position, m-block) tiles to fill 256 CUs.
+// Returns the number of z-slices; *kcps = padded input channels per slice.
+int plan_ksplit(int blocks, int cinp, int kc, int* kcps)
+{
+    const int nchunks = cinp / kc;
+    *kcps = cinp;
+    if (blocks >= 192 || nchunks < 4) return 1;
+    const int want = (512 + blocks - 1) / blocks;
+    int cps = (nchunks + want - 1) / want;
+    if (cps < 2) cps = 2;
+    const int ks = (nchunks + cps - 1) / cps;
+    if (ks <= 1) return 1;
+    *kcps = cps * kc;
+    return ks;
 }
 
 SrcDesc layer_src(const wunet_ctx* c, int i, float* ws, const float* noisy)
@@ -180,42 +199,82 @@ int launch_conv_any(int taps, int mode, const ConvArgs& a, int mrep, int nrep, d
     return 0;
 }
 
-int launch_wgrad_any(int taps, int mode, const WgradArgs& a, int mrep, dim3 grid, hipStream_t st)
+WgradArgs make_wgrad_args(const float* x, const float* g, float* part, int B, int Cin, int Cout, int L, int taps, int cps)
 {
-    const int cib = 24;
-    const size_t smem = ((size_t)mrep * 16 * 66 + (size_t)cib * a.geo.rowp) * sizeof(float);
-    int rc = -1;
+    WgradArgs a{};
+    a.x = x; a.g = g; a.part = part; a.B = B; a.Cin = Cin; a.Cout = Cout; a.L = L; a.logL = ilog2(L);
+    a.chunks_per_split = cps;
+    a.seg = L < 64 ? L : 64;
+    a.seg_shift = ilog2(a.seg);
+    a.segw = a.seg + 16;
+    const int nseg = 64 / a.seg;
+    a.r4 = nseg * a.segw / 4;
+    a.sw4 = a.segw / 4;
+    int rp = a.r4 * 4;
+    if (taps == 5) while (rp % 32 != 8) rp += 4;     // 3 ci rows per n-tile land on disjoint banks
+    a.rowp = rp;
+    a.r4_magic = (unsigned)(((1u << 20) + a.r4 - 1) / a.r4);
+    a.sw4_magic = (unsigned)(((1u << 20) + a.sw4 - 1) / a.sw4);
+    return a;
+}
+
+int launch_wgrad_any(int taps, const WgradArgs& a, const WgradCfg& w, hipStream_t st)
+{
+    const int cib = w.wsplit ? 1 : 4 * w.nw * (taps == 15 ? 1 : 3);
+    const size_t smem = ((size_t)w.mrep * 16 * 66 + (size_t)cib * a.rowp) * sizeof(float);
     char pname[96];
-    snprintf(pname, sizeof pname, "wgrad_mfma_kernel<%d, %d, %d, %d>", taps, mode, mrep, taps == 15 ? 6 : 2);
-    const double posn = (double)a.B * a.x.L;
-    prof_begin(st, pname, 2.0 * posn * a.Cout * a.Cin * taps, 4.0 * posn * (2.0 * a.Cout + a.Cin));
-    if (taps == 15 && mode == SRC_RAW) rc = wunet_launch_wgrad_15_0(a, mrep, grid, smem, st);
-    else if (taps == 15 && mode == SRC_DECIM) rc = wunet_launch_wgrad_15_1(a, mrep, grid, smem, st);
-    else if (taps == 5 && mode == SRC_UPCAT) rc = wunet_launch_wgrad_5_2(a, mrep, grid, smem, st);
-    else if (taps == 5 && mode == SRC_RAW) rc = wunet_launch_wgrad_5_0(a, mrep, grid, smem, st);
+    snprintf(pname, sizeof pname, "wgrad_mfma_kernel<%d, %d, %d, %d, %s>", taps, w.mrep, w.nw, w.xit, w.wsplit ? "true" : "false");
+    const double posn = (double)a.B * a.L;
+    prof_begin(st, pname, 2.0 * posn * a.Cout * a.Cin * taps, 4.0 * posn * (a.Cout + a.Cin));
+    const dim3 grid(w.ksplit, w.nblocks, w.mblocks);
+    int rc = taps == 15 ? wunet_launch_wgrad_15(a, w.mrep, w.nw, w.xit, w.wsplit, grid, smem, st)
+                        : wunet_launch_wgrad_5(a, w.mrep, w.nw, w.xit, w.wsplit, grid, smem, st);
     prof_end(st);
-    if (rc != 0) return fail(WUNET_E_ARG, "no wgrad kernel for taps=%d mode=%d mrep=%d", taps, mode, mrep);
+    if (rc != 0) return fail(WUNET_E_ARG, "no wgrad kernel for taps=%d mrep=%d nw=%d xit=%d wsplit=%d", taps, w.mrep, w.nw, w.xit, w.wsplit);
     return 0;
 }
 
 int mode_of(int kind) { return kind == LK_RAW ? SRC_RAW : (kind == LK_DECIM ? SRC_DECIM : SRC_UPCAT); }
 
-struct WgradCfg { int mrep, mblocks, nblocks, ksplit, cps; };
-
-WgradCfg plan_wgrad(int B, int L, int cin, int cout)
+WgradCfg plan_wgrad(int B, int L, int cin, int cout, int taps)
 {
-    WgradCfg w;
+    WgradCfg w{};
     const int mt = (cout + 15) / 16;
-    w.mrep = pick_mrep(mt, 6);
-    w.mblocks = round_up(mt, w.mrep) / w.mrep;
-    w.nblocks = (cin + 23) / 24;
+    const int nt = taps == 15 ? cin : (cin + 2) / 3;         // n-tiles of 16 (ci,tap) columns
     const long long chunks = ((long long)B * L + 63) / 64;
+    const bool big = L >= 64;
+    if (taps == 15 && cin == 1) {
+        // encoder[0]: a single n-tile - the four waves split the K steps instead
+        w.wsplit = 1; w.nw = 1; w.xit = 1;
+        w.mrep = pick_mrep(mt, 6);
+        w.mblocks = round_up(mt, w.mrep) / w.mrep;
+        w.nblocks = 1;
+    } else {
+        const int nws[2] = {taps == 15 ? 6 : 2, (taps == 5 && big) ? 6 : 0};
+        long long best = -1; int best_area = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int nw = nws[k];
+            if (!nw) continue;
+            for (int mr = 2; mr <= 6; ++mr) {
+                if (mr * nw > 36) continue;
+                const long long padded = (long long)round_up(mt, mr) * round_up(nt, 4 * nw);
+                if (best < 0 || padded < best || (padded == best && mr * nw > best_area)) {
+                    best = padded; best_area = mr * nw; w.mrep = mr; w.nw = nw;
+                }
+            }
+        }
+        w.wsplit = 0;
+        w.mblocks = round_up(mt, w.mrep) / w.mrep;
+        w.nblocks = round_up(nt, 4 * w.nw) / (4 * w.nw);
+        w.xit = big ? (w.nw == 6 && taps == 5 ? 6 : 2) : 8;
+    }
     long long want = 1024 / ((long long)w.mblocks * w.nblocks);
     if (want < 1) want = 1;
     long long ks = 1;
     while (ks * 2 <= want && ks * 2 <= chunks) ks *= 2;
     w.ksplit = (int)ks;
     w.cps = (int)((chunks + ks - 1) / ks);
+    w.rows = w.ksplit * (w.wsplit ? 4 : 1);
     return w;
 }
 
@@ -254,7 +313,7 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         }
         l.logL = ilog2(l.L);
     }
-    size_t off = 0, wpk = 0, stats_max = 0;
+    size_t off = 0, wpk = 0, stats_max = 0, spart_max = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
         const int kc = kc_of(l.taps);
@@ -267,9 +326,22 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         const int tn = 64 * l.f_nrep;
         l.f_grid_x = (int)(((long long)B * l.L + tn - 1) / tn);
         l.f_rows = l.f_grid_x * WUNET_WAVES;
+        l.f_ksplit = plan_ksplit(l.f_grid_x * l.f_mblocks, l.f_cinp, kc, &l.f_kcps);
+        if (l.f_ksplit > 1 && (size_t)l.f_ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f_ksplit * B * l.cout * l.L;
         l.f_wpk = wpk;
         wpk += align64((size_t)l.f_mtiles_p * l.f_cinp * l.taps * 16);
         if ((size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
+        {   // data-gradient tiling (rows = cin, K-channels = cout); planned here so the split buffer covers it
+            const int dmt = (l.cin + 15) / 16;
+            l.d_mrep = pick_mrep(dmt, 6);
+            l.d_mtiles_p = round_up(dmt, l.d_mrep);
+            l.d_mblocks = l.d_mtiles_p / l.d_mrep;
+            l.d_nrep = conv_nrep(B, l.L, l.d_mblocks);
+            l.d_cp = round_up(l.cout, kc);
+            l.d_grid_x = (int)(((long long)B * l.L + 64 * l.d_nrep - 1) / (64 * l.d_nrep));
+            l.d_ksplit = plan_ksplit(l.d_grid_x * l.d_mblocks, l.d_cp, kc, &l.d_kcps);
+            if (i > 0 && l.d_ksplit > 1 && (size_t)l.d_ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d_ksplit * B * l.cin * l.L;
+        }
         l.z = off; off += align64((size_t)B * l.cout * l.L);
         l.a = off; off += align64(l.cout);
         l.s = off; off += align64(l.cout);
@@ -278,9 +350,10 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
     }
     c->stats_off = off; off += align64(stats_max);
     c->wpkf_off = off; off += align64(wpk);
+    c->spart_off = off; off += align64(spart_max);
     c->fwd_floats = off;
 
-    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0;
+    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0, gz_max = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
         const int kc = kc_of(l.taps);
@@ -289,20 +362,13 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         l.k1 = off; off += align64(l.cout);
         l.k2 = off; off += align64(l.cout);
         l.k3 = off; off += align64(l.cout);
-        // dgrad: rows = cin
-        const int mt = (l.cin + 15) / 16;
-        l.d_mrep = pick_mrep(mt, 6);
-        l.d_mtiles_p = round_up(mt, l.d_mrep);
-        l.d_mblocks = l.d_mtiles_p / l.d_mrep;
-        l.d_nrep = conv_nrep(B, l.L, l.d_mblocks);
-        l.d_cp = round_up(l.cout, kc);
-        l.d_grid_x = (int)(((long long)B * l.L + 64 * l.d_nrep - 1) / (64 * l.d_nrep));
+        (void)kc;
         l.d_wpk = wpkb;
         if (i > 0) wpkb += align64((size_t)l.d_mtiles_p * l.d_cp * l.taps * 16);
-        const WgradCfg w = plan_wgrad(B, l.L, l.cin, l.cout);
-        l.w_mrep = w.mrep; l.w_mblocks = w.mblocks; l.w_nblocks = w.nblocks; l.w_ksplit = w.ksplit; l.w_cps = w.cps;
-        l.w_nw = l.taps == 15 ? 6 : 2;
-        const size_t wg = (size_t)l.w_ksplit * l.cout * l.cin * l.taps;
+        l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
+        l.xin = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);
+        if ((size_t)B * l.cout * l.L > gz_max) gz_max = (size_t)B * l.cout * l.L;
+        const size_t wg = (size_t)l.w.rows * l.cout * l.cin * l.taps;
         if (wg > wgpart_max) wgpart_max = wg;
         long long sp = ((long long)B * l.L) / 4096;
         l.a_split = (int)(sp < 1 ? 1 : (sp > 64 ? 64 : sp));
@@ -317,6 +383,7 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         c->head_blocks = (int)(hb < 1 ? 1 : (hb > 1024 ? 1024 : hb));
     }
     c->hpart_off = off; off += align64((size_t)c->head_blocks * (ci + 2));
+    c->gz_off = off; off += align64(gz_max);
     c->total_floats = off;
     *out = c;
     return WUNET_OK;
@@ -342,7 +409,7 @@ int wunet_layer_info(const wunet_ctx* ctx, int layer, size_t* z_offset_floats, i
 }
 
 int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, float* const* running,
-                  long long* const* nbt, int training, void* workspace, float* enhanced, void* stream)
+                  long long* const* nbt, int training, int save_for_backward, void* workspace, float* enhanced, void* stream)
 {
     if (!c || !noisy || !params || !running || !nbt || !workspace || !enhanced) return fail(WUNET_E_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
@@ -370,7 +437,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         a.out = ws + l.z;
         a.stats = training ? ws + c->stats_off : nullptr;
         a.B = c->B; a.Cout = l.cout; a.CinP = l.f_cinp;
-        int rc = launch_conv_any(l.taps, mode_of(l.kind), a, l.f_mrep, l.f_nrep, dim3(l.f_grid_x, l.f_mblocks), st);
+        a.kc_per_split = l.f_kcps; a.split_stride = (size_t)c->B * l.cout * l.L;
+        a.xout = (save_for_backward && i > 0) ? ws + l.xin : nullptr;   // activated conv input, kept for the weight gradient
+        if (l.f_ksplit > 1) { a.bias = nullptr; a.out = ws + c->spart_off; a.stats = nullptr; }
+        int rc = launch_conv_any(l.taps, mode_of(l.kind), a, l.f_mrep, l.f_nrep, dim3(l.f_grid_x, l.f_mblocks, l.f_ksplit), st);
         if (rc) return rc;
         WUNET_CHECK_LAUNCH();
         BnFwdArgs b{};
@@ -379,7 +449,12 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         b.running_mean = running[2 * i]; b.running_var = running[2 * i + 1]; b.nbt = nbt[i];
         b.a = ws + l.a; b.s = ws + l.s; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
         b.C = l.cout; b.count = (double)c->B * l.L; b.training = training ? 1 : 0;
-        WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
+        if (l.f_ksplit > 1) {
+            WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
+                         l.f_ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL);
+        } else {
+            WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
+        }
         WUNET_CHECK_LAUNCH();
     }
     // 3. head
@@ -429,7 +504,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         WUNET_LAUNCH(head_bwd_kernel, dim3(c->head_blocks), dim3(WUNET_THREADS), 0, st, h);
         WUNET_CHECK_LAUNCH();
         const int nh = c->ci + 2;
-        WUNET_LAUNCH(rows_sum_kernel, dim3((nh + WUNET_THREADS - 1) / WUNET_THREADS), dim3(WUNET_THREADS), 0, st,
+        WUNET_LAUNCH(rows_sum_kernel, dim3(nh), dim3(WUNET_THREADS), 0, st,
                      (const float*)(ws + c->hpart_off), c->head_blocks, nh, grads[4 * NL], c->ci + 1, grads[4 * NL + 1]);
         WUNET_CHECK_LAUNCH();
     }
@@ -458,12 +533,9 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         WUNET_CHECK_LAUNCH();
         BnBwdArgs b{};
         b.part = ws + c->bpart_off; b.rows = l.a_split; b.gamma = params[4 * i + 2]; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
-        b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
+        b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
         b.C = l.cout; b.count = (double)c->B * l.L;
         WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
-        WUNET_CHECK_LAUNCH();
-        // conv bias feeding training-mode BatchNorm: gradient is exactly zero
-        WUNET_LAUNCH(fill_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, grads[4 * i + 1], (size_t)l.cout, 0.0f);
         WUNET_CHECK_LAUNCH();
 
         const SrcDesc gz = gz_src(ws + l.g, ws + l.z, ws + l.k1, ws + l.k2, ws + l.k3, l.cout, l.L);
@@ -474,25 +546,40 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             a.geo = make_geom(l.L, 64 * l.d_nrep, l.taps / 2, 0, 16);
             a.wpk = ws + c->wpkb_off + l.d_wpk; a.bias = nullptr; a.out = ws + l.dx; a.stats = nullptr;
             a.B = c->B; a.Cout = l.cin; a.CinP = l.d_cp;
-            int rc = launch_conv_any(l.taps, SRC_GZ, a, l.d_mrep, l.d_nrep, dim3(l.d_grid_x, l.d_mblocks), st);
+            a.kc_per_split = l.d_kcps; a.split_stride = (size_t)c->B * l.cin * l.L;
+            a.xout = ws + c->gz_off;          // g_z materialised for the weight gradient
+            if (l.d_ksplit > 1) a.out = ws + c->spart_off;
+            int rc = launch_conv_any(l.taps, SRC_GZ, a, l.d_mrep, l.d_nrep, dim3(l.d_grid_x, l.d_mblocks, l.d_ksplit), st);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
+            if (l.d_ksplit > 1) {
+                const size_t nd = (size_t)c->B * l.cin * l.L;
+                size_t blocks = (nd + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (blocks > 2048) blocks = 2048;
+                WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + c->spart_off), l.d_ksplit, nd, ws + l.dx);
+                WUNET_CHECK_LAUNCH();
+            }
         }
-        // ---- weight gradient: split-K partials + deterministic reduce
+        else {
+            const size_t ng = (size_t)c->B * l.cout * l.L;
+            size_t blocks = (ng + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
+            if (blocks > 4096) blocks = 4096;
+            WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, ng, ws + c->gz_off);
+            WUNET_CHECK_LAUNCH();
+        }
+        // ---- weight gradient: GEMM over positions on the materialised operands, split-K partials + deterministic reduce
         {
-            WgradArgs w{};
-            w.x = layer_src(c, i, ws, noisy);
-            w.g = gz;
-            w.geo = make_geom(l.L, 64, l.taps / 2, 1, l.taps == 15 ? 16 : 8);
-            w.part = ws + c->wgpart_off; w.B = c->B; w.Cout = l.cout; w.Cin = l.cin; w.chunks_per_split = l.w_cps;
-            int rc = launch_wgrad_any(l.taps, mode_of(l.kind), w, l.w_mrep, dim3(l.w_ksplit, l.w_nblocks, l.w_mblocks), st);
+            const float* xin = i == 0 ? noisy : ws + l.xin;
+            const WgradArgs w = make_wgrad_args(xin, ws + c->gz_off, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
+            int rc = launch_wgrad_any(l.taps, w, l.w, st);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
             const size_t nw = (size_t)l.cout * l.cin * l.taps;
             size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 2048) blocks = 2048;
             WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st,
-                         (const float*)(ws + c->wgpart_off), l.w_ksplit, nw, grads[4 * i]);
+                         (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
             WUNET_CHECK_LAUNCH();
         }
     }
@@ -600,6 +687,7 @@ int wunet_op_conv1d(const float* x, const float* w, const float* bias, float* z,
     a.src.p0 = x; a.src.C = Cin; a.src.C0 = Cin; a.src.L = L; a.src.Lsrc0 = L; a.src.logL = ilog2(L);
     a.geo = make_geom(L, 64 * nrep, K / 2, 0, 16);
     a.wpk = wpk; a.bias = bias; a.out = z; a.stats = nullptr; a.B = B; a.Cout = Cout; a.CinP = cinp;
+    a.kc_per_split = cinp; a.split_stride = 0; a.xout = nullptr;
     const int gx = (int)(((long long)B * L + 64 * nrep - 1) / (64 * nrep));
     int rc = launch_conv_any(K, SRC_RAW, a, mrep, nrep, dim3(gx, mblocks), st);
     hipStreamSynchronize(st);
@@ -636,6 +724,7 @@ int wunet_op_conv1d_dgrad(const float* gz, const float* w, float* dx, int B, int
     a.src = gz_src(gz, gz, k1, k0, k0, Cout, L);
     a.geo = make_geom(L, 64 * nrep, K / 2, 0, 16);
     a.wpk = wpk; a.bias = nullptr; a.out = dx; a.stats = nullptr; a.B = B; a.Cout = Cin; a.CinP = cp;
+    a.kc_per_split = cp; a.split_stride = 0; a.xout = nullptr;
     const int gx = (int)(((long long)B * L + 64 * nrep - 1) / (64 * nrep));
     int rc = launch_conv_any(K, SRC_GZ, a, mrep, nrep, dim3(gx, mblocks), st);
     hipStreamSynchronize(st);
@@ -649,24 +738,19 @@ int wunet_op_conv1d_wgrad(const float* gz, const float* x, float* dw, int B, int
 {
     if (op_check(B, Cin, Cout, L, K)) return WUNET_E_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const WgradCfg cfg = plan_wgrad(B, L, Cin, Cout);
-    float *part = nullptr, *k1 = nullptr, *k0 = nullptr;
+    const WgradCfg cfg = plan_wgrad(B, L, Cin, Cout, K);
+    float* part = nullptr;
     const size_t nw = (size_t)Cout * Cin * K;
-    if (hipMalloc((void**)&part, (size_t)cfg.ksplit * nw * sizeof(float)) != hipSuccess) return fail(WUNET_E_RUNTIME, "hipMalloc");
-    if (make_unit_gz(Cout, &k1, &k0, st)) return WUNET_E_RUNTIME;
-    WgradArgs a{};
-    a.x.p0 = x; a.x.C = Cin; a.x.C0 = Cin; a.x.L = L; a.x.Lsrc0 = L; a.x.logL = ilog2(L);
-    a.g = gz_src(gz, gz, k1, k0, k0, Cout, L);
-    a.geo = make_geom(L, 64, K / 2, 1, K == 15 ? 16 : 8);
-    a.part = part; a.B = B; a.Cout = Cout; a.Cin = Cin; a.chunks_per_split = cfg.cps;
-    int rc = launch_wgrad_any(K, SRC_RAW, a, cfg.mrep, dim3(cfg.ksplit, cfg.nblocks, cfg.mblocks), st);
+    if (hipMalloc((void**)&part, (size_t)cfg.rows * nw * sizeof(float)) != hipSuccess) return fail(WUNET_E_RUNTIME, "hipMalloc");
+    const WgradArgs a = make_wgrad_args(x, gz, part, B, Cin, Cout, L, K, cfg.cps);
+    int rc = launch_wgrad_any(K, a, cfg, st);
     if (!rc) {
         size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
         if (blocks > 2048) blocks = 2048;
-        WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)part, cfg.ksplit, nw, dw);
+        WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)part, cfg.rows, nw, dw);
     }
     hipStreamSynchronize(st);
-    hipFree(part); hipFree(k1); hipFree(k0);
+    hipFree(part);
     if (rc) return rc;
     WUNET_CHECK_LAUNCH();
     return WUNET_OK;

@@ -26,7 +26,8 @@ __device__ __forceinline__ float wunet_shfl_xor(float v, int mask) { return __sh
 #define WUNET_WAVES 4
 #define WUNET_SLOPE 0.1f
 
-__device__ __forceinline__ float wunet_lrelu(float v) { return v > 0.0f ? v : WUNET_SLOPE * v; }
+// LeakyReLU(0.1): slope < 1 so max(v, 0.1 v) is exact and branch-free
+__device__ __forceinline__ float wunet_lrelu(float v) { return fmaxf(v, WUNET_SLOPE * v); }
 
 // ATen upsample_linear1d(align_corners=True) source coordinate, fp32 arithmetic on purpose
 // (reference model/unet_basic.py:93 -> ATen UpSample.h area_pixel_compute_source_index +

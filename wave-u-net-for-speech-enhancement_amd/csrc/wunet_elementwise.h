@@ -84,17 +84,39 @@ struct BnFwdArgs {
     int training;
 };
 
+// thread 0 of the block owning channel c: turn (sum, sum of squares) of the bias-free conv into everything BN needs
+__device__ __forceinline__ void bn_finalize_core(const BnFwdArgs& A, int c, double s1, double s2)
+{
+    const double m0 = s1 / A.count;                   // mean of the bias-free conv
+    double var = s2 / A.count - m0 * m0;              // biased variance (bias does not change it)
+    var = var < 0.0 ? 0.0 : var;
+    const double mean = m0 + (double)A.bias[c];
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float a = A.gamma[c] * rstd;
+    A.a[c] = a;
+    A.s[c] = A.beta[c] - (float)mean * a;
+    A.mean[c] = (float)mean;
+    A.rstd[c] = rstd;
+    const double unbiased = A.count > 1.0 ? var * A.count / (A.count - 1.0) : var;
+    A.running_mean[c] = (float)(0.9 * (double)A.running_mean[c] + 0.1 * mean);
+    A.running_var[c] = (float)(0.9 * (double)A.running_var[c] + 0.1 * unbiased);
+    if (c == 0) *A.nbt += 1;
+}
+
+__device__ __forceinline__ void bn_eval_core(const BnFwdArgs& A, int c)
+{
+    const float rstd = (float)(1.0 / sqrt((double)A.running_var[c] + 1e-5));
+    const float a = A.gamma[c] * rstd;
+    A.a[c] = a;
+    A.s[c] = A.beta[c] - A.running_mean[c] * a;
+}
+
 __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
     if (!A.training) {
-        if (tid == 0) {
-            const float rstd = (float)(1.0 / sqrt((double)A.running_var[c] + 1e-5));
-            const float a = A.gamma[c] * rstd;
-            A.a[c] = a;
-            A.s[c] = A.beta[c] - A.running_mean[c] * a;
-        }
+        if (tid == 0) bn_eval_core(A, c);
         return;
     }
     double s1 = 0.0, s2 = 0.0;
@@ -104,21 +126,43 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArg
         s2 += (double)st[1];
     }
     block_sum2(s1, s2, red);
+    if (tid == 0) bn_finalize_core(A, c, s1, s2);
+}
+
+// Split-K forward conv of the short levels: sum the z-slices' partial outputs, add the bias, write z and
+// finish BatchNorm in the same launch (grid = C; the whole channel, B*L <= a few thousand values, is
+// reduced by one block).
+__global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
+                                                                        size_t split_stride, float* z, int B, int L, int logL)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float bias = A.bias[c];
+    double s1 = 0.0, s2 = 0.0;
+    const int total = B * L;
+    for (int p = tid; p < total; p += WUNET_THREADS) {
+        const int b = p >> logL, l = p & (L - 1);
+        const size_t off = ((size_t)b * A.C + c) * L + l;
+        float v = 0.0f;
+        for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * split_stride + off];
+        z[off] = v + bias;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+    }
+    block_sum2(s1, s2, red);
     if (tid == 0) {
-        const double m0 = s1 / A.count;                   // mean of the bias-free conv
-        double var = s2 / A.count - m0 * m0;              // biased variance (bias does not change it)
-        var = var < 0.0 ? 0.0 : var;
-        const double mean = m0 + (double)A.bias[c];
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-        const float a = A.gamma[c] * rstd;
-        A.a[c] = a;
-        A.s[c] = A.beta[c] - (float)mean * a;
-        A.mean[c] = (float)mean;
-        A.rstd[c] = rstd;
-        const double unbiased = A.count > 1.0 ? var * A.count / (A.count - 1.0) : var;
-        A.running_mean[c] = (float)(0.9 * (double)A.running_mean[c] + 0.1 * mean);
-        A.running_var[c] = (float)(0.9 * (double)A.running_var[c] + 0.1 * unbiased);
-        if (c == 0) *A.nbt += 1;
+        if (A.training) bn_finalize_core(A, c, s1, s2);
+        else bn_eval_core(A, c);
+    }
+}
+
+// sum of split-K partial tensors (data gradient of the short levels)
+__global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* part, int ksplit, size_t n, float* out)
+{
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
+        float v = 0.0f;
+        for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * n + i];
+        out[i] = v;
     }
 }
 
@@ -201,14 +245,17 @@ __global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdArgs A)
     }
 }
 
-// sums partial rows: out[j] = sum_r part[r][j]   (grid = ceil(n/256))
+// sums partial rows: out[j] = sum_r part[r][j]   (grid = n, one block per column)
 __global__ __launch_bounds__(WUNET_THREADS) void rows_sum_kernel(const float* part, int rows, int n, float* out0, int n0, float* out1)
 {
-    const int j = blockIdx.x * WUNET_THREADS + threadIdx.x;
-    if (j >= n) return;
-    double s = 0.0;
-    for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * n + j];
-    if (j < n0) out0[j] = (float)s; else out1[j - n0] = (float)s;
+    __shared__ double red[2 * WUNET_THREADS];
+    const int j = blockIdx.x;
+    double s = 0.0, dummy = 0.0;
+    for (int r = threadIdx.x; r < rows; r += WUNET_THREADS) s += (double)part[(size_t)r * n + j];
+    block_sum2(s, dummy, red);
+    if (threadIdx.x == 0) {
+        if (j < n0) out0[j] = (float)s; else out1[j - n0] = (float)s;
+    }
 }
 
 // ---------------------------------------------------------------------------- pass A (gradient assembly)
@@ -293,6 +340,7 @@ struct BnBwdArgs {
     const float* part; int rows;
     const float* gamma; const float* mean; const float* rstd;
     float* dgamma; float* dbeta;
+    float* dbias;        // conv bias feeding training-mode BN: exact zero gradient
     float* k1; float* k2; float* k3;
     int C; double count;
 };
@@ -311,6 +359,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArg
     if (tid == 0) {
         A.dgamma[c] = (float)s2;
         A.dbeta[c] = (float)s1;
+        A.dbias[c] = 0.0f;
         const double m1 = s1 / A.count, m2 = s2 / A.count;
         const double a = (double)A.gamma[c] * (double)A.rstd[c];
         A.k1[c] = (float)a;
@@ -335,6 +384,17 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float
         }
         for (; r < splits; ++r) tot += (double)part[(size_t)r * n + i];
         dw[i] = (float)tot;
+    }
+}
+
+// g_z = k1*g + k2*z + k3 materialised (only the first layer needs it: every other layer's data-gradient
+// kernel writes g_z as a side effect of its loader)
+__global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
+                                                                        const float* k3, int C, int logL, size_t n, float* gz)
+{
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const int c = (int)((i >> logL) % (size_t)C);
+        gz[i] = k1[c] * g[i] + k2[c] * z[i] + k3[c];
     }
 }
 

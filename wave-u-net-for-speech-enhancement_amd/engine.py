@@ -84,7 +84,7 @@ class Engine:
         out = torch.empty_like(noisy)
         with self._device_guard(noisy.device):
             self._check(self.lib.wunet_forward(h, noisy.data_ptr(), self._ptrs(params), self._ptrs(running),
-                                               self._ptrs(nbt), 1 if training else 0, ws.data_ptr(),
+                                               self._ptrs(nbt), 1 if training else 0, 1 if with_backward else 0, ws.data_ptr(),
                                                out.data_ptr(), self._stream(noisy.device)))
         return out, ws
 
