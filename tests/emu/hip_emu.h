@@ -55,6 +55,10 @@ struct wunet_f4 {
     const float& operator[](int i) const { return v[i]; }
 };
 
+inline wunet_f4 wunet_ld4(const float* p) { wunet_f4 r; std::memcpy(r.v, p, 16); return r; }
+inline void wunet_st4(float* p, wunet_f4 v) { std::memcpy(p, v.v, 16); }
+inline wunet_f4 wunet_sel4(bool ok, wunet_f4 v) { return ok ? v : wunet_f4{{0.f, 0.f, 0.f, 0.f}}; }
+
 inline wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
 {
     emu::FiberState& f = emu::cur_fiber();

@@ -63,6 +63,7 @@ int ilog2(long long v) { int r = 0; while ((1LL << r) < v) ++r; return r; }
 bool is_pow2(long long v) { return v > 0 && (v & (v - 1)) == 0; }
 size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 int round_up(int v, int m) { return (v + m - 1) / m * m; }
+int kc_of(int taps) { return taps == 15 ? 4 : 12; }
 
 // m-tiles (16 output channels each) handled per block: minimise zero padding, prefer bigger blocks.
 int pick_mrep(int mtiles, int max_rep)
@@ -75,128 +76,139 @@ int pick_mrep(int mtiles, int max_rep)
     return best;
 }
 
-TileGeom make_geom(int L, int TN, int pad, int extra_cols, int row_mod)
+// Tiling of one implicit-GEMM conv: rows = output channels of the GEMM, kch = its K channels.
+struct ConvCfg { int mrep, nrep, mtiles_p, mblocks, cp, grid_x, ksplit, kcps; };
+
+ConvCfg plan_conv(int B, int L, int rows, int kch, int taps)
 {
-    TileGeom g;
-    g.seg = L < TN ? L : TN;
-    g.seg_shift = ilog2(g.seg);
-    g.nseg = TN / g.seg;
-    g.segw = g.seg + 2 * pad;
-    g.rowlen = g.nseg * g.segw + extra_cols;
-    int rp = g.rowlen;
-    while (rp % 32 != row_mod) ++rp;
-    g.rowp = rp;
-    g.segw_magic = (unsigned)(((1u << 20) + g.segw - 1) / g.segw);
-    return g;
-}
-
-enum { LK_RAW = 0, LK_DECIM = 1, LK_UPCAT = 2 };
-
-struct WgradCfg { int mrep, nw, xit, wsplit, mblocks, nblocks, ksplit, cps, rows; };
-
-struct LayerPlan {
-    int cin, cout, taps, L, logL, kind;
-    int src0, src1;      // producer layers (src0 = -1: network input)
-    int c0;              // UPCAT: channels from the upsampled branch
-    // forward conv
-    int f_mrep, f_nrep, f_mblocks, f_cinp, f_mtiles_p, f_grid_x, f_rows, f_ksplit, f_kcps;
-    size_t f_wpk;
-    // data gradient (rows = cin, K-channels = cout)
-    int d_mrep, d_nrep, d_mblocks, d_cp, d_mtiles_p, d_grid_x, d_ksplit, d_kcps;
-    size_t d_wpk;
-    // weight gradient
-    WgradCfg w;
-    size_t xin;          // materialised activated conv input [B][cin][L] (layers >= 1), float offset
-    // pass A
-    int a_split;
-    // workspace (float offsets)
-    size_t z, a, s, mean, rstd, g, dx, k1, k2, k3;
-};
-
-}  // namespace
-
-struct wunet_ctx {
-    int n, ci, B, T, NL;
-    std::vector<LayerPlan> ly;
-    size_t stats_off, wpkf_off, spart_off, fwd_floats;
-    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, gz_off, total_floats;
-    int head_blocks;
-};
-
-namespace {
-
-int kc_of(int taps) { return taps == 15 ? 4 : 12; }
-
-int conv_nrep(int B, int L, int mblocks)
-{
+    ConvCfg c{};
+    const int kc = kc_of(taps);
+    const int mt = (rows + 15) / 16;
+    c.mrep = pick_mrep(mt, 6);
+    c.mtiles_p = round_up(mt, c.mrep);
+    c.mblocks = c.mtiles_p / c.mrep;
+    c.cp = round_up(kch, kc);
     const long long pos = (long long)B * L;
-    return (L >= 256 && (pos / 256) * mblocks >= 256) ? 4 : 1;
-}
-
-// split-K over input-channel chunks when a layer has too few (position, m-block) tiles to fill 256 CUs.
-// Returns the number of z-slices; *kcps = padded input channels per slice.
-int plan_ksplit(int blocks, int cinp, int kc, int* kcps)
-{
-    const int nchunks = cinp / kc;
-    *kcps = cinp;
-    if (blocks >= 192 || nchunks < 4) return 1;
-    const int want = (512 + blocks - 1) / blocks;
-    int cps = (nchunks + want - 1) / want;
-    if (cps < 2) cps = 2;
-    const int ks = (nchunks + cps - 1) / cps;
-    if (ks <= 1) return 1;
-    *kcps = cps * kc;
-    return ks;
-}
-
-SrcDesc layer_src(const wunet_ctx* c, int i, float* ws, const float* noisy)
-{
-    const LayerPlan& l = c->ly[i];
-    SrcDesc d{};
-    d.C = l.cin; d.L = l.L; d.logL = l.logL; d.C0 = l.cin; d.Lsrc0 = l.L; d.up_scale = 0.f;
-    if (l.kind == LK_RAW) {
-        d.p0 = noisy;
-    } else if (l.kind == LK_DECIM) {
-        const LayerPlan& p = c->ly[l.src0];
-        d.p0 = ws + p.z; d.a0 = ws + p.a; d.s0 = ws + p.s; d.Lsrc0 = 2 * l.L;
-    } else {
-        const LayerPlan& p = c->ly[l.src0];
-        const LayerPlan& k = c->ly[l.src1];
-        d.p0 = ws + p.z; d.a0 = ws + p.a; d.s0 = ws + p.s;
-        d.p1 = ws + k.z; d.a1 = ws + k.a; d.s1 = ws + k.s;
-        d.C0 = l.c0; d.Lsrc0 = l.L / 2;
-        d.up_scale = l.L > 1 ? (float)(d.Lsrc0 - 1) / (float)(l.L - 1) : 0.f;
+    const int nchunks = c.cp / kc;
+    // 256-position tiles (N_REP=4) reuse every A fragment 4x; usable when the staged row fits the loader
+    // (k15: L >= 16, k5: L >= 64) and - counting the split-K factor available - the grid still fills the chip
+    const bool wide_ok = (taps == 15 ? L >= 16 : L >= 64) && pos >= 256;
+    const long long tiles4 = ((pos + 255) / 256) * c.mblocks;
+    const int ksmax = nchunks >= 4 ? (nchunks / 2 < 16 ? nchunks / 2 : 16) : 1;
+    c.nrep = (wide_ok && tiles4 * ksmax >= 256) ? 4 : 1;
+    const int tn = 64 * c.nrep;
+    c.grid_x = (int)((pos + tn - 1) / tn);
+    // split-K over input-channel chunks when there are too few (position, m-block) tiles to fill 256 CUs
+    const int blocks = c.grid_x * c.mblocks;
+    c.ksplit = 1; c.kcps = c.cp;
+    if (blocks < 192 && nchunks >= 4) {
+        const int want = (512 + blocks - 1) / blocks;
+        int cps = (nchunks + want - 1) / want;
+        if (cps < 2) cps = 2;
+        const int ks = (nchunks + cps - 1) / cps;
+        if (ks > 1) { c.ksplit = ks; c.kcps = cps * kc; }
     }
-    return d;
+    return c;
 }
 
-SrcDesc gz_src(const float* g, const float* z, const float* k1, const float* k2, const float* k3, int C, int L)
+ConvArgs make_conv_args(const float* x, int kch, const float* wpk, const float* bias, float* out, float* stats,
+                        int B, int rows, int L, int taps, const ConvCfg& c, size_t split_stride)
 {
-    SrcDesc d{};
-    d.p0 = g; d.a0 = k1; d.s0 = k2; d.p1 = z; d.a1 = k3;
-    d.C = C; d.C0 = C; d.L = L; d.Lsrc0 = L; d.logL = ilog2(L);
-    return d;
+    ConvArgs a{};
+    a.x = x; a.wpk = wpk; a.bias = bias; a.out = out; a.stats = stats;
+    a.B = B; a.Cin = kch; a.Cout = rows; a.CinP = c.cp; a.L = L; a.logL = ilog2(L);
+    const int tn = 64 * c.nrep;
+    a.seg = L < tn ? L : tn;
+    a.seg_shift = ilog2(a.seg);
+    a.segw = a.seg + 16;
+    const int rowlen = (tn / a.seg) * a.segw;
+    int rp = rowlen;
+    while (rp % 32 != 16) rp += 4;
+    a.rowp = rp;
+    a.r4 = rowlen / 4;
+    a.sw4 = a.segw / 4;
+    a.r4_magic = (unsigned)(((1u << 20) + a.r4 - 1) / a.r4);
+    a.sw4_magic = (unsigned)(((1u << 20) + a.sw4 - 1) / a.sw4);
+    a.kc_per_split = c.kcps;
+    a.split_stride = split_stride;
+    return a;
 }
 
-int launch_conv_any(int taps, int mode, const ConvArgs& a, int mrep, int nrep, dim3 grid, hipStream_t st)
+int launch_conv(int taps, const char* what, const ConvArgs& a, const ConvCfg& c, hipStream_t st)
 {
     const int kc = kc_of(taps);
     char pname[96];
-    snprintf(pname, sizeof pname, "conv_mfma_kernel<%d, %d, %d, %d>", taps, mode, mrep, nrep);
-    // algorithmic work: 2*B*L*Cout*Cin*taps flops; the virtual input read once + the output written once
-    const double posn = (double)a.B * a.src.L;
-    prof_begin(st, pname, 2.0 * posn * a.Cout * a.src.C * taps, 4.0 * posn * (a.Cout + a.src.C));
-    const size_t smem = ((size_t)kc * a.geo.rowp + (size_t)mrep * kc * taps * 16) * sizeof(float);
-    int rc = -1;
-    if (taps == 15 && mode == SRC_RAW) rc = wunet_launch_conv_15_0(a, mrep, nrep, grid, smem, st);
-    else if (taps == 15 && mode == SRC_DECIM) rc = wunet_launch_conv_15_1(a, mrep, nrep, grid, smem, st);
-    else if (taps == 5 && mode == SRC_UPCAT) rc = wunet_launch_conv_5_2(a, mrep, nrep, grid, smem, st);
-    else if (taps == 15 && mode == SRC_GZ) rc = wunet_launch_conv_15_3(a, mrep, nrep, grid, smem, st);
-    else if (taps == 5 && mode == SRC_GZ) rc = wunet_launch_conv_5_3(a, mrep, nrep, grid, smem, st);
-    else if (taps == 5 && mode == SRC_RAW) rc = wunet_launch_conv_5_0(a, mrep, nrep, grid, smem, st);
+    snprintf(pname, sizeof pname, "conv_mfma_kernel<%d, %d, %d>", taps, c.mrep, c.nrep);
+    (void)what;
+    // algorithmic work: 2*B*L*rows*kch*taps flops; input read once + output written once
+    const double posn = (double)a.B * a.L;
+    prof_begin(st, pname, 2.0 * posn * a.Cout * a.Cin * taps, 4.0 * posn * (a.Cout + a.Cin));
+    const size_t smem = ((size_t)kc * a.rowp + (size_t)c.mrep * kc * taps * 16) * sizeof(float);
+    const dim3 grid(c.grid_x, c.mblocks, c.ksplit);
+    const int rc = taps == 15 ? wunet_launch_conv_15(a, c.mrep, c.nrep, grid, smem, st)
+                              : wunet_launch_conv_5(a, c.mrep, c.nrep, grid, smem, st);
     prof_end(st);
-    if (rc != 0) return fail(WUNET_E_ARG, "no conv kernel for taps=%d mode=%d mrep=%d nrep=%d", taps, mode, mrep, nrep);
+    if (rc != 0) return fail(WUNET_E_ARG, "no conv kernel for taps=%d mrep=%d nrep=%d", taps, c.mrep, c.nrep);
     return 0;
+}
+
+struct WgradCfg { int mrep, nw, xit, wsplit, mblocks, nblocks, ksplit, cps, rows; };
+
+WgradCfg plan_wgrad(int B, int L, int cin, int cout, int taps)
+{
+    WgradCfg w{};
+    const int mt = (cout + 15) / 16;
+    const int nt = taps == 15 ? cin : (cin + 2) / 3;         // n-tiles of 16 (ci,tap) columns
+    const long long chunks = ((long long)B * L + 63) / 64;
+    const bool big = L >= 64;
+    if (taps == 15 && cin == 1) {
+        // encoder[0]: a single n-tile - the four waves split the K steps instead
+        w.wsplit = 1; w.nw = 1; w.xit = 1;
+        w.mrep = pick_mrep(mt, 6);
+        w.mblocks = round_up(mt, w.mrep) / w.mrep;
+        w.nblocks = 1;
+    } else {
+        const int nws[2] = {taps == 15 ? 6 : 2, (taps == 5 && big) ? 6 : 0};
+        long long best = -1; int best_area = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int nw = nws[k];
+            if (!nw) continue;
+            for (int mr = 2; mr <= 6; ++mr) {
+                if (mr * nw > 36) continue;
+                const long long padded = (long long)round_up(mt, mr) * round_up(nt, 4 * nw);
+                if (best < 0 || padded < best || (padded == best && mr * nw > best_area)) {
+                    best = padded; best_area = mr * nw; w.mrep = mr; w.nw = nw;
+                }
+            }
+        }
+        w.wsplit = 0;
+        w.mblocks = round_up(mt, w.mrep) / w.mrep;
+        w.nblocks = round_up(nt, 4 * w.nw) / (4 * w.nw);
+        w.xit = big ? (w.nw == 6 && taps == 5 ? 6 : 2) : 8;
+    }
+    // split-K: one resident wave of equal-work blocks.  Residency estimate: accumulators + staging registers
+    // against the 512-entry register file per SIMD lane, and the LDS footprint against 160 KiB.
+    {
+        const int regs = 4 * w.mrep * w.nw + 72 + 4 * (w.mrep + w.xit);
+        int occ = regs <= 168 ? 3 : (regs <= 256 ? 2 : 1);
+        const int segw = (L < 64 ? L : 64) + 16;
+        const int rowp = (64 / (L < 64 ? L : 64)) * segw + (taps == 5 ? 24 : 0);
+        const int cib = w.wsplit ? 1 : 4 * w.nw * (taps == 15 ? 1 : 3);
+        const long long lds = ((long long)w.mrep * 16 * 66 + (long long)cib * rowp) * 4;
+        const int occ_lds = (int)(160 * 1024 / lds);
+        if (occ_lds < occ) occ = occ_lds < 1 ? 1 : occ_lds;
+        const long long slots = 256LL * occ;
+        const long long mn = (long long)w.mblocks * w.nblocks;
+        long long ks = slots / mn;
+        if (ks < 1) ks = 1;
+        if (ks > chunks) ks = chunks;
+        w.ksplit = (int)ks;
+        w.cps = (int)((chunks + ks - 1) / ks);
+        // drop splits that would only run padding chunks
+        w.ksplit = (int)((chunks + w.cps - 1) / w.cps);
+    }
+    w.rows = w.ksplit * (w.wsplit ? 4 : 1);
+    return w;
 }
 
 WgradArgs make_wgrad_args(const float* x, const float* g, float* part, int B, int Cin, int Cout, int L, int taps, int cps)
@@ -234,51 +246,31 @@ int launch_wgrad_any(int taps, const WgradArgs& a, const WgradCfg& w, hipStream_
     return 0;
 }
 
-int mode_of(int kind) { return kind == LK_RAW ? SRC_RAW : (kind == LK_DECIM ? SRC_DECIM : SRC_UPCAT); }
+enum { LK_RAW = 0, LK_DECIM = 1, LK_UPCAT = 2 };
 
-WgradCfg plan_wgrad(int B, int L, int cin, int cout, int taps)
-{
-    WgradCfg w{};
-    const int mt = (cout + 15) / 16;
-    const int nt = taps == 15 ? cin : (cin + 2) / 3;         // n-tiles of 16 (ci,tap) columns
-    const long long chunks = ((long long)B * L + 63) / 64;
-    const bool big = L >= 64;
-    if (taps == 15 && cin == 1) {
-        // encoder[0]: a single n-tile - the four waves split the K steps instead
-        w.wsplit = 1; w.nw = 1; w.xit = 1;
-        w.mrep = pick_mrep(mt, 6);
-        w.mblocks = round_up(mt, w.mrep) / w.mrep;
-        w.nblocks = 1;
-    } else {
-        const int nws[2] = {taps == 15 ? 6 : 2, (taps == 5 && big) ? 6 : 0};
-        long long best = -1; int best_area = 0;
-        for (int k = 0; k < 2; ++k) {
-            const int nw = nws[k];
-            if (!nw) continue;
-            for (int mr = 2; mr <= 6; ++mr) {
-                if (mr * nw > 36) continue;
-                const long long padded = (long long)round_up(mt, mr) * round_up(nt, 4 * nw);
-                if (best < 0 || padded < best || (padded == best && mr * nw > best_area)) {
-                    best = padded; best_area = mr * nw; w.mrep = mr; w.nw = nw;
-                }
-            }
-        }
-        w.wsplit = 0;
-        w.mblocks = round_up(mt, w.mrep) / w.mrep;
-        w.nblocks = round_up(nt, 4 * w.nw) / (4 * w.nw);
-        w.xit = big ? (w.nw == 6 && taps == 5 ? 6 : 2) : 8;
-    }
-    long long want = 1024 / ((long long)w.mblocks * w.nblocks);
-    if (want < 1) want = 1;
-    long long ks = 1;
-    while (ks * 2 <= want && ks * 2 <= chunks) ks *= 2;
-    w.ksplit = (int)ks;
-    w.cps = (int)((chunks + ks - 1) / ks);
-    w.rows = w.ksplit * (w.wsplit ? 4 : 1);
-    return w;
-}
+struct LayerPlan {
+    int cin, cout, taps, L, logL, kind;
+    int src0, src1;      // producer layers (src0 = -1: network input)
+    int c0;              // UPCAT: channels from the upsampled branch
+    ConvCfg f;           // forward conv (rows = cout, K channels = cin)
+    ConvCfg d;           // data gradient (rows = cin, K channels = cout)
+    WgradCfg w;          // weight gradient
+    int f_rows;          // BN statistics partial rows written by the forward conv
+    int a_split;         // pass A position splits
+    size_t f_wpk, d_wpk; // float offsets inside the forward / backward weight packs
+    // workspace (float offsets)
+    size_t z, a, s, mean, rstd, xin, g, dx, k1, k2, k3;
+};
 
 }  // namespace
+
+struct wunet_ctx {
+    int n, ci, B, T, NL;
+    std::vector<LayerPlan> ly;
+    size_t stats_off, wpkf_off, spart_off, fwd_floats;
+    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, gz_off, total_floats;
+    int head_blocks;
+};
 
 extern "C" {
 
@@ -316,37 +308,22 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
     size_t off = 0, wpk = 0, stats_max = 0, spart_max = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
-        const int kc = kc_of(l.taps);
-        const int mt = (l.cout + 15) / 16;
-        l.f_mrep = pick_mrep(mt, 6);
-        l.f_mtiles_p = round_up(mt, l.f_mrep);
-        l.f_mblocks = l.f_mtiles_p / l.f_mrep;
-        l.f_nrep = conv_nrep(B, l.L, l.f_mblocks);
-        l.f_cinp = round_up(l.cin, kc);
-        const int tn = 64 * l.f_nrep;
-        l.f_grid_x = (int)(((long long)B * l.L + tn - 1) / tn);
-        l.f_rows = l.f_grid_x * WUNET_WAVES;
-        l.f_ksplit = plan_ksplit(l.f_grid_x * l.f_mblocks, l.f_cinp, kc, &l.f_kcps);
-        if (l.f_ksplit > 1 && (size_t)l.f_ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f_ksplit * B * l.cout * l.L;
+        l.f = plan_conv(B, l.L, l.cout, l.cin, l.taps);
+        l.d = plan_conv(B, l.L, l.cin, l.cout, l.taps);
+        l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
+        l.f_rows = l.f.grid_x * WUNET_WAVES;
         l.f_wpk = wpk;
-        wpk += align64((size_t)l.f_mtiles_p * l.f_cinp * l.taps * 16);
-        if ((size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
-        {   // data-gradient tiling (rows = cin, K-channels = cout); planned here so the split buffer covers it
-            const int dmt = (l.cin + 15) / 16;
-            l.d_mrep = pick_mrep(dmt, 6);
-            l.d_mtiles_p = round_up(dmt, l.d_mrep);
-            l.d_mblocks = l.d_mtiles_p / l.d_mrep;
-            l.d_nrep = conv_nrep(B, l.L, l.d_mblocks);
-            l.d_cp = round_up(l.cout, kc);
-            l.d_grid_x = (int)(((long long)B * l.L + 64 * l.d_nrep - 1) / (64 * l.d_nrep));
-            l.d_ksplit = plan_ksplit(l.d_grid_x * l.d_mblocks, l.d_cp, kc, &l.d_kcps);
-            if (i > 0 && l.d_ksplit > 1 && (size_t)l.d_ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d_ksplit * B * l.cin * l.L;
-        }
+        wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
+        if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
+        if (l.f.ksplit > 1 && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
+        if (l.f.ksplit > 1 && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
+        if (i > 0 && l.d.ksplit > 1 && (size_t)l.d.ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d.ksplit * B * l.cin * l.L;
         l.z = off; off += align64((size_t)B * l.cout * l.L);
         l.a = off; off += align64(l.cout);
         l.s = off; off += align64(l.cout);
         l.mean = off; off += align64(l.cout);
         l.rstd = off; off += align64(l.cout);
+        l.xin = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
     }
     c->stats_off = off; off += align64(stats_max);
     c->wpkf_off = off; off += align64(wpk);
@@ -356,17 +333,13 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
     size_t wpkb = 0, bpart_max = 0, wgpart_max = 0, gz_max = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
-        const int kc = kc_of(l.taps);
         l.g = off; off += align64((size_t)B * l.cout * l.L);
         l.dx = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);
         l.k1 = off; off += align64(l.cout);
         l.k2 = off; off += align64(l.cout);
         l.k3 = off; off += align64(l.cout);
-        (void)kc;
         l.d_wpk = wpkb;
-        if (i > 0) wpkb += align64((size_t)l.d_mtiles_p * l.d_cp * l.taps * 16);
-        l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
-        l.xin = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);
+        if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
         if ((size_t)B * l.cout * l.L > gz_max) gz_max = (size_t)B * l.cout * l.L;
         const size_t wg = (size_t)l.w.rows * l.cout * l.cin * l.taps;
         if (wg > wgpart_max) wgpart_max = wg;
@@ -412,6 +385,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                   long long* const* nbt, int training, int save_for_backward, void* workspace, float* enhanced, void* stream)
 {
     if (!c || !noisy || !params || !running || !nbt || !workspace || !enhanced) return fail(WUNET_E_ARG, "null argument");
+    (void)save_for_backward;   // everything the backward needs (z, BN statistics, conv inputs) lives in the forward segment
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     // 1. pack all forward weights into MFMA-fragment order (one launch)
@@ -421,37 +395,62 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             const LayerPlan& l = c->ly[i];
             PackDesc& d = tab.d[i];
             d.w = params[4 * i]; d.dst = ws + c->wpkf_off + l.f_wpk;
-            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cout; d.CP = l.f_cinp; d.mtiles = l.f_mtiles_p; d.transposed = 0;
+            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cout; d.CP = l.f.cp; d.mtiles = l.f.mtiles_p; d.transposed = 0;
         }
         WUNET_LAUNCH(pack_weights_kernel, dim3(128, c->NL), dim3(WUNET_THREADS), 0, st, tab);
         WUNET_CHECK_LAUNCH();
     }
-    // 2. conv (+ fused BN/LeakyReLU/decimate/upsample/concat on load) and BN statistics per layer
     for (int i = 0; i < c->NL; ++i) {
         const LayerPlan& l = c->ly[i];
-        ConvArgs a{};
-        a.src = layer_src(c, i, ws, noisy);
-        a.geo = make_geom(l.L, 64 * l.f_nrep, l.taps / 2, 0, 16);
-        a.wpk = ws + c->wpkf_off + l.f_wpk;
-        a.bias = params[4 * i + 1];
-        a.out = ws + l.z;
-        a.stats = training ? ws + c->stats_off : nullptr;
-        a.B = c->B; a.Cout = l.cout; a.CinP = l.f_cinp;
-        a.kc_per_split = l.f_kcps; a.split_stride = (size_t)c->B * l.cout * l.L;
-        a.xout = (save_for_backward && i > 0) ? ws + l.xin : nullptr;   // activated conv input, kept for the weight gradient
-        if (l.f_ksplit > 1) { a.bias = nullptr; a.out = ws + c->spart_off; a.stats = nullptr; }
-        int rc = launch_conv_any(l.taps, mode_of(l.kind), a, l.f_mrep, l.f_nrep, dim3(l.f_grid_x, l.f_mblocks, l.f_ksplit), st);
+        // 2a. materialise the conv input: BN scale/shift + LeakyReLU + decimation, or + x2 upsample + skip concat
+        const float* xin = noisy;
+        if (i > 0) {
+            const LayerPlan& p = c->ly[l.src0];
+            PrepArgs pa{};
+            pa.z0 = ws + p.z; pa.a0 = ws + p.a; pa.s0 = ws + p.s; pa.x = ws + l.xin;
+            pa.B = c->B; pa.C0 = l.c0; pa.C1 = l.cin - l.c0; pa.L = l.L; pa.logL = l.logL;
+            const size_t n4 = (size_t)c->B * l.cin * l.L / 4;
+            size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
+            if (blocks > 8192) blocks = 8192;
+            if (l.kind == LK_DECIM) {
+                WUNET_LAUNCH(prep_decim_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa);
+            } else {
+                const LayerPlan& k = c->ly[l.src1];
+                pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
+                pa.up_scale = l.L > 1 ? (float)(l.L / 2 - 1) / (float)(l.L - 1) : 0.f;
+                WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa);
+            }
+            WUNET_CHECK_LAUNCH();
+            xin = ws + l.xin;
+        }
+        // 2b. conv (+ bias, + per-wave BN statistics partials) on the matrix cores
+        const bool split = l.f.ksplit > 1;
+        const ConvArgs a = make_conv_args(xin, l.cin, ws + c->wpkf_off + l.f_wpk, split ? nullptr : params[4 * i + 1],
+                                          split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr,
+                                          c->B, l.cout, l.L, l.taps, l.f, (size_t)c->B * l.cout * l.L);
+        int rc = launch_conv(l.taps, "fwd", a, l.f, st);
         if (rc) return rc;
         WUNET_CHECK_LAUNCH();
+        // 2c. BatchNorm statistics -> scale/shift for the consumers (+ running stats)
         BnFwdArgs b{};
         b.stats = ws + c->stats_off; b.rows = l.f_rows; b.bias = params[4 * i + 1];
         b.gamma = params[4 * i + 2]; b.beta = params[4 * i + 3];
         b.running_mean = running[2 * i]; b.running_var = running[2 * i + 1]; b.nbt = nbt[i];
         b.a = ws + l.a; b.s = ws + l.s; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
         b.C = l.cout; b.count = (double)c->B * l.L; b.training = training ? 1 : 0;
-        if (l.f_ksplit > 1) {
-            WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
-                         l.f_ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL);
+        if (split) {
+            // sum the z-slices (+bias -> z) and reduce the BN statistics; short levels finish BN in the same launch
+            const long long pos = (long long)c->B * l.L;
+            int rs = (int)(pos / 2048);
+            if (rs < 1) rs = 1;
+            if (rs > 64) rs = 64;
+            b.rows = rs;
+            WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout, rs), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
+                         l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off);
+            if (rs > 1) {
+                WUNET_CHECK_LAUNCH();
+                WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
+            }
         } else {
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
@@ -490,7 +489,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             const LayerPlan& l = c->ly[i];
             PackDesc& d = tab.d[nd++];
             d.w = params[4 * i]; d.dst = ws + c->wpkb_off + l.d_wpk;
-            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cin; d.CP = l.d_cp; d.mtiles = l.d_mtiles_p; d.transposed = 1;
+            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cin; d.CP = l.d.cp; d.mtiles = l.d.mtiles_p; d.transposed = 1;
         }
         if (nd > 0) {
             WUNET_LAUNCH(pack_weights_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
@@ -538,35 +537,30 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         WUNET_CHECK_LAUNCH();
 
-        const SrcDesc gz = gz_src(ws + l.g, ws + l.z, ws + l.k1, ws + l.k2, ws + l.k3, l.cout, l.L);
-        // ---- data gradient (not needed for the first layer)
+        // ---- g_z = k1*g + k2*z + k3, materialised once for both gradient GEMMs
+        {
+            const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
+            size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
+            if (blocks > 8192) blocks = 8192;
+            WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + c->gz_off);
+            WUNET_CHECK_LAUNCH();
+        }
+        // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
         if (i > 0) {
-            ConvArgs a{};
-            a.src = gz;
-            a.geo = make_geom(l.L, 64 * l.d_nrep, l.taps / 2, 0, 16);
-            a.wpk = ws + c->wpkb_off + l.d_wpk; a.bias = nullptr; a.out = ws + l.dx; a.stats = nullptr;
-            a.B = c->B; a.Cout = l.cin; a.CinP = l.d_cp;
-            a.kc_per_split = l.d_kcps; a.split_stride = (size_t)c->B * l.cin * l.L;
-            a.xout = ws + c->gz_off;          // g_z materialised for the weight gradient
-            if (l.d_ksplit > 1) a.out = ws + c->spart_off;
-            int rc = launch_conv_any(l.taps, SRC_GZ, a, l.d_mrep, l.d_nrep, dim3(l.d_grid_x, l.d_mblocks, l.d_ksplit), st);
+            const bool split = l.d.ksplit > 1;
+            const size_t nd = (size_t)c->B * l.cin * l.L;
+            const ConvArgs a = make_conv_args(ws + c->gz_off, l.cout, ws + c->wpkb_off + l.d_wpk, nullptr,
+                                              split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.L, l.taps, l.d, nd);
+            int rc = launch_conv(l.taps, "dgrad", a, l.d, st);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
-            if (l.d_ksplit > 1) {
-                const size_t nd = (size_t)c->B * l.cin * l.L;
+            if (split) {
                 size_t blocks = (nd + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (blocks > 2048) blocks = 2048;
-                WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + c->spart_off), l.d_ksplit, nd, ws + l.dx);
+                WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + c->spart_off), l.d.ksplit, nd, ws + l.dx, (const float*)nullptr, 1, 0);
                 WUNET_CHECK_LAUNCH();
             }
-        }
-        else {
-            const size_t ng = (size_t)c->B * l.cout * l.L;
-            size_t blocks = (ng + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
-            if (blocks > 4096) blocks = 4096;
-            WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, ng, ws + c->gz_off);
-            WUNET_CHECK_LAUNCH();
         }
         // ---- weight gradient: GEMM over positions on the materialised operands, split-K partials + deterministic reduce
         {
@@ -670,68 +664,45 @@ static int op_check(int B, int Cin, int Cout, int L, int K)
     return 0;
 }
 
-int wunet_op_conv1d(const float* x, const float* w, const float* bias, float* z, int B, int Cin, int Cout, int L, int K, void* stream)
+static int op_conv_common(const float* x, const float* w, const float* bias, float* out, int B, int kch, int rows,
+                          int Cout, int Cin, int L, int K, int transposed, hipStream_t st)
 {
-    if (op_check(B, Cin, Cout, L, K)) return WUNET_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int kc = kc_of(K), mt = (Cout + 15) / 16;
-    const int mrep = pick_mrep(mt, 6), mtp = round_up(mt, mrep), mblocks = mtp / mrep;
-    const int nrep = conv_nrep(B, L, mblocks), cinp = round_up(Cin, kc);
-    float* wpk = nullptr;
-    if (hipMalloc((void**)&wpk, (size_t)mtp * cinp * K * 16 * sizeof(float)) != hipSuccess) return fail(WUNET_E_RUNTIME, "hipMalloc");
+    const ConvCfg cfg = plan_conv(B, L, rows, kch, K);
+    float *wpk = nullptr, *part = nullptr;
+    if (hipMalloc((void**)&wpk, (size_t)cfg.mtiles_p * cfg.cp * K * 16 * sizeof(float)) != hipSuccess) return fail(WUNET_E_RUNTIME, "hipMalloc");
+    const size_t nout = (size_t)B * rows * L;
+    if (cfg.ksplit > 1 && hipMalloc((void**)&part, (size_t)cfg.ksplit * nout * sizeof(float)) != hipSuccess) return fail(WUNET_E_RUNTIME, "hipMalloc");
     PackTable tab{};
     PackDesc& d = tab.d[0];
-    d.w = w; d.dst = wpk; d.Cout = Cout; d.Cin = Cin; d.taps = K; d.M = Cout; d.CP = cinp; d.mtiles = mtp; d.transposed = 0;
+    d.w = w; d.dst = wpk; d.Cout = Cout; d.Cin = Cin; d.taps = K; d.M = rows; d.CP = cfg.cp; d.mtiles = cfg.mtiles_p; d.transposed = transposed;
     WUNET_LAUNCH(pack_weights_kernel, dim3(64, 1), dim3(WUNET_THREADS), 0, st, tab);
-    ConvArgs a{};
-    a.src.p0 = x; a.src.C = Cin; a.src.C0 = Cin; a.src.L = L; a.src.Lsrc0 = L; a.src.logL = ilog2(L);
-    a.geo = make_geom(L, 64 * nrep, K / 2, 0, 16);
-    a.wpk = wpk; a.bias = bias; a.out = z; a.stats = nullptr; a.B = B; a.Cout = Cout; a.CinP = cinp;
-    a.kc_per_split = cinp; a.split_stride = 0; a.xout = nullptr;
-    const int gx = (int)(((long long)B * L + 64 * nrep - 1) / (64 * nrep));
-    int rc = launch_conv_any(K, SRC_RAW, a, mrep, nrep, dim3(gx, mblocks), st);
+    const bool split = cfg.ksplit > 1;
+    const ConvArgs a = make_conv_args(x, kch, wpk, split ? nullptr : bias, split ? part : out, nullptr, B, rows, L, K, cfg, nout);
+    int rc = launch_conv(K, "op", a, cfg, st);
+    if (!rc && split) {
+        size_t blocks = (nout + WUNET_THREADS - 1) / WUNET_THREADS;
+        if (blocks > 2048) blocks = 2048;
+        WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)part, cfg.ksplit, nout, out,
+                     bias, rows, ilog2(L));
+    }
     hipStreamSynchronize(st);
     hipFree(wpk);
+    if (part) hipFree(part);
     if (rc) return rc;
     WUNET_CHECK_LAUNCH();
     return WUNET_OK;
 }
 
-static int make_unit_gz(int C, float** k1, float** k0, hipStream_t st)
+int wunet_op_conv1d(const float* x, const float* w, const float* bias, float* z, int B, int Cin, int Cout, int L, int K, void* stream)
 {
-    if (hipMalloc((void**)k1, C * sizeof(float)) != hipSuccess || hipMalloc((void**)k0, C * sizeof(float)) != hipSuccess)
-        return fail(WUNET_E_RUNTIME, "hipMalloc");
-    WUNET_LAUNCH(fill_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, *k1, (size_t)C, 1.0f);
-    WUNET_LAUNCH(fill_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, *k0, (size_t)C, 0.0f);
-    return 0;
+    if (op_check(B, Cin, Cout, L, K)) return WUNET_E_ARG;
+    return op_conv_common(x, w, bias, z, B, Cin, Cout, Cout, Cin, L, K, 0, (hipStream_t)stream);
 }
 
 int wunet_op_conv1d_dgrad(const float* gz, const float* w, float* dx, int B, int Cin, int Cout, int L, int K, void* stream)
 {
     if (op_check(B, Cin, Cout, L, K)) return WUNET_E_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const int kc = kc_of(K), mt = (Cin + 15) / 16;
-    const int mrep = pick_mrep(mt, 6), mtp = round_up(mt, mrep), mblocks = mtp / mrep;
-    const int nrep = conv_nrep(B, L, mblocks), cp = round_up(Cout, kc);
-    float *wpk = nullptr, *k1 = nullptr, *k0 = nullptr;
-    if (hipMalloc((void**)&wpk, (size_t)mtp * cp * K * 16 * sizeof(float)) != hipSuccess) return fail(WUNET_E_RUNTIME, "hipMalloc");
-    if (make_unit_gz(Cout, &k1, &k0, st)) return WUNET_E_RUNTIME;
-    PackTable tab{};
-    PackDesc& d = tab.d[0];
-    d.w = w; d.dst = wpk; d.Cout = Cout; d.Cin = Cin; d.taps = K; d.M = Cin; d.CP = cp; d.mtiles = mtp; d.transposed = 1;
-    WUNET_LAUNCH(pack_weights_kernel, dim3(64, 1), dim3(WUNET_THREADS), 0, st, tab);
-    ConvArgs a{};
-    a.src = gz_src(gz, gz, k1, k0, k0, Cout, L);
-    a.geo = make_geom(L, 64 * nrep, K / 2, 0, 16);
-    a.wpk = wpk; a.bias = nullptr; a.out = dx; a.stats = nullptr; a.B = B; a.Cout = Cin; a.CinP = cp;
-    a.kc_per_split = cp; a.split_stride = 0; a.xout = nullptr;
-    const int gx = (int)(((long long)B * L + 64 * nrep - 1) / (64 * nrep));
-    int rc = launch_conv_any(K, SRC_GZ, a, mrep, nrep, dim3(gx, mblocks), st);
-    hipStreamSynchronize(st);
-    hipFree(wpk); hipFree(k1); hipFree(k0);
-    if (rc) return rc;
-    WUNET_CHECK_LAUNCH();
-    return WUNET_OK;
+    return op_conv_common(gz, w, nullptr, dx, B, Cout, Cin, Cout, Cin, L, K, 1, (hipStream_t)stream);
 }
 
 int wunet_op_conv1d_wgrad(const float* gz, const float* x, float* dw, int B, int Cin, int Cout, int L, int K, void* stream)

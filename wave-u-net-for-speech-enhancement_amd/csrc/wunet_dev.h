@@ -20,6 +20,12 @@ __device__ __forceinline__ wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float wunet_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// 16-byte staging registers are the NATIVE vector type: arrays of HIP's float4 struct carried across loop
+// iterations were demoted to scratch memory by hipcc (global_load -> vmcnt(0) -> scratch_store), which
+// silently serialised the software pipeline.
+__device__ __forceinline__ wunet_f4 wunet_ld4(const float* p) { return *reinterpret_cast<const wunet_f4*>(p); }
+__device__ __forceinline__ void wunet_st4(float* p, wunet_f4 v) { *reinterpret_cast<wunet_f4*>(p) = v; }
+__device__ __forceinline__ wunet_f4 wunet_sel4(bool ok, wunet_f4 v) { return ok ? v : wunet_f4{0.f, 0.f, 0.f, 0.f}; }
 #endif
 
 #define WUNET_THREADS 256

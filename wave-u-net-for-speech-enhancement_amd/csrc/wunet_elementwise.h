@@ -129,18 +129,21 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArg
     if (tid == 0) bn_finalize_core(A, c, s1, s2);
 }
 
-// Split-K forward conv of the short levels: sum the z-slices' partial outputs, add the bias, write z and
-// finish BatchNorm in the same launch (grid = C; the whole channel, B*L <= a few thousand values, is
-// reduced by one block).
+// Split-K forward conv: sum the z-slices' partial outputs, add the bias, write z, and reduce the BatchNorm
+// statistics.  grid = (C, rsplit): with rsplit == 1 (short levels) BatchNorm is finished in the same launch,
+// otherwise each block writes one partial row [blockIdx.y][C][2] for bn_finalize_fwd_kernel.
 __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
-                                                                        size_t split_stride, float* z, int B, int L, int logL)
+                                                                        size_t split_stride, float* z, int B, int L, int logL,
+                                                                        float* stats_rows)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float bias = A.bias[c];
     double s1 = 0.0, s2 = 0.0;
     const int total = B * L;
-    for (int p = tid; p < total; p += WUNET_THREADS) {
+    const int per = (total + gridDim.y - 1) / gridDim.y;
+    const int beg = blockIdx.y * per, end = beg + per < total ? beg + per : total;
+    for (int p = beg + tid; p < end; p += WUNET_THREADS) {
         const int b = p >> logL, l = p & (L - 1);
         const size_t off = ((size_t)b * A.C + c) * L + l;
         float v = 0.0f;
@@ -151,18 +154,23 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
     }
     block_sum2(s1, s2, red);
     if (tid == 0) {
-        if (A.training) bn_finalize_core(A, c, s1, s2);
+        if (gridDim.y > 1) {
+            float* st = stats_rows + ((size_t)blockIdx.y * A.C + c) * 2;
+            st[0] = (float)s1;
+            st[1] = (float)s2;
+        } else if (A.training) bn_finalize_core(A, c, s1, s2);
         else bn_eval_core(A, c);
     }
 }
 
 // sum of split-K partial tensors (data gradient of the short levels)
-__global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* part, int ksplit, size_t n, float* out)
+__global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* part, int ksplit, size_t n, float* out,
+                                                                   const float* bias, int C, int logL)
 {
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
         float v = 0.0f;
         for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * n + i];
-        out[i] = v;
+        out[i] = v + (bias ? bias[(i >> logL) % (size_t)C] : 0.0f);
     }
 }
 
@@ -387,14 +395,82 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float
     }
 }
 
-// g_z = k1*g + k2*z + k3 materialised (only the first layer needs it: every other layer's data-gradient
-// kernel writes g_z as a side effect of its loader)
-__global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
-                                                                        const float* k3, int C, int logL, size_t n, float* gz)
+// ---------------------------------------------------------------------------- conv input materialisation
+// One fused pass per layer builds the tensor its conv consumes (and its weight gradient re-reads):
+//   encoder i+1 / middle : x[b,c,l] = lrelu(a[c]*z[b,c,2l] + s[c])                (unet_basic.py:13,86)
+//   decoder j            : c <  C0: l0*act(zp[b,c,i0]) + l1*act(zp[b,c,i1])        (unet_basic.py:93, ATen fp32 coordinates)
+//                          c >= C0: lrelu(a1*zs[b,c-C0,l] + s1)                    (unet_basic.py:95 cat([up, skip]))
+// Each thread produces one aligned float4 of x.
+struct PrepArgs {
+    const float* z0; const float* a0; const float* s0;   // producer (previous level) raw conv output + BN scale/shift
+    const float* z1; const float* a1; const float* s1;   // skip producer (decoder only)
+    float* x;                                            // [B][C0+C1][L]
+    int B, C0, C1, L, logL;
+    float up_scale;                                      // (float)(L/2-1)/(L-1)
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
 {
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
-        const int c = (int)((i >> logL) % (size_t)C);
-        gz[i] = k1[c] * g[i] + k2[c] * z[i] + k3[c];
+    const int l4n = A.L >> 2;
+    const size_t total = (size_t)A.B * A.C0 * l4n;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const size_t row = i >> (A.logL - 2);
+        const int l4 = (int)(i & (size_t)(l4n - 1));
+        const int c = (int)(row % (size_t)A.C0);
+        const float a = A.a0[c], s = A.s0[c];
+        const float4* src = reinterpret_cast<const float4*>(A.z0 + row * (size_t)(2 * A.L) + 8 * l4);
+        const float4 u = src[0], v = src[1];
+        float4 o;
+        o.x = wunet_lrelu(a * u.x + s); o.y = wunet_lrelu(a * u.z + s);
+        o.z = wunet_lrelu(a * v.x + s); o.w = wunet_lrelu(a * v.z + s);
+        reinterpret_cast<float4*>(A.x)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A)
+{
+    const int l4n = A.L >> 2, C = A.C0 + A.C1, Lh = A.L >> 1;
+    const size_t total = (size_t)A.B * C * l4n;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const size_t row = i >> (A.logL - 2);
+        const int l4 = (int)(i & (size_t)(l4n - 1));
+        const int b = (int)(row / (size_t)C), c = (int)(row - (size_t)b * C);
+        float4 o;
+        if (c < A.C0) {
+            const float a = A.a0[c], s = A.s0[c];
+            const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int i0, i1; float l0, l1;
+                wunet_up_coord(4 * l4 + j, Lh, A.up_scale, i0, i1, l0, l1);
+                r[j] = l0 * wunet_lrelu(a * zr[i0] + s) + l1 * wunet_lrelu(a * zr[i1] + s);
+            }
+            o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+        } else {
+            const int cs = c - A.C0;
+            const float a = A.a1[cs], s = A.s1[cs];
+            const float4 v = reinterpret_cast<const float4*>(A.z1 + ((size_t)b * A.C1 + cs) * A.L)[l4];
+            o.x = wunet_lrelu(a * v.x + s); o.y = wunet_lrelu(a * v.y + s);
+            o.z = wunet_lrelu(a * v.z + s); o.w = wunet_lrelu(a * v.w + s);
+        }
+        reinterpret_cast<float4*>(A.x)[i] = o;
+    }
+}
+
+// g_z = k1*g + k2*z + k3 (BatchNorm backward folded to three per-channel coefficients), materialised once
+// per layer for its data-gradient and weight-gradient GEMMs
+__global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
+                                                                        const float* k3, int C, int logL, size_t n4, float* gz)
+{
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const int c = (int)((i >> (logL - 2)) % (size_t)C);
+        const float a = k1[c], b = k2[c], d = k3[c];
+        const float4 gv = reinterpret_cast<const float4*>(g)[i], zv = reinterpret_cast<const float4*>(z)[i];
+        float4 o;
+        o.x = a * gv.x + b * zv.x + d; o.y = a * gv.y + b * zv.y + d;
+        o.z = a * gv.z + b * zv.z + d; o.w = a * gv.w + b * zv.w + d;
+        reinterpret_cast<float4*>(gz)[i] = o;
     }
 }
 

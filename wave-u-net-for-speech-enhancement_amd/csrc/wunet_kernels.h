@@ -1,227 +1,86 @@
 // MFMA kernels of the Wave-U-Net hot path for gfx950 (CDNA4).
 //
 //   conv_mfma_kernel  : z = W (*) x  as an implicit GEMM  M=Cout, N=B*L positions, K=Cin*taps
-//                       (forward conv of every layer, and - with flipped/transposed packed weights
-//                       and the GZ loader - the data gradient of every layer).
+//                       (forward conv of every layer and - with the flipped/transposed weight pack
+//                       and x = g_z - the data gradient of every layer).
 //   wgrad_mfma_kernel : dW = g_z (*) x  as a GEMM  M=Cout, N=(ci,tap), K=B*L positions.
 //
-// Both read a *virtual* input: BatchNorm scale/shift + LeakyReLU + decimation ([:, :, ::2]) or
-// linear x2 upsample + skip concat are applied while staging the tile into LDS, so none of those
-// tensors is ever materialised (reference model/unet_basic.py:82-96 materialises all of them).
+// All three GEMMs read MATERIALISED operands: one fused elementwise kernel per layer (prep_*_kernel)
+// writes the conv's activated input x = decimate / upsample+concat of LeakyReLU(BN(z_prev)) once and the
+// forward conv and the weight gradient both consume it; gz_materialize_kernel writes the BatchNorm-backward
+// gradient g_z once for the data gradient and the weight gradient.  Measured on MI355X this beats loaders
+// that re-derive those values inside the GEMM (the path is MFMA-bound at 3 % of HBM bandwidth, so bytes
+// are cheap and issue slots beside the matrix pipe are not): PMC showed 20-35 % of wave cycles issuing
+// loader VALU/VMEM and 25-45 % parked for the fused form against 12-16 % / 11-17 % for the pure GEMM.
 // The MFMA is v_mfma_f32_16x16x4_f32: exact fp32 (an fmaf chain), 157 TF peak = fp32 vector peak.
 //
 // Layouts (all fp32, reference layout (batch, channel, sample), sample contiguous):
 //   packed weights  [m-tile][ci (padded to KC)][tap][16 co]   -> a K-chunk of one m-tile is one
 //                   contiguous run, A fragments are bank-conflict free (tap stride 16 dwords with
 //                   TAPS odd => the two k-quarters of a 32-lane group land on disjoint bank halves).
-//   LDS x tile      [ci][rowp], rowp == 16 (mod 32)           -> B fragments conflict free.
+//   LDS x tile      [ci][rowp], rowp == 16 (mod 32), each segment staged with 8 floats of halo on both
+//                   sides so every global load / LDS store is an aligned float4.
 #pragma once
 #include "wunet_dev.h"
 
-enum { SRC_RAW = 0, SRC_DECIM = 1, SRC_UPCAT = 2, SRC_GZ = 3 };
-
-// Virtual input x[b, c, l], c < C, l < L.
-//  RAW   : p0[b, c, l]                                             (network input, encoder[0])
-//  DECIM : lrelu(a0[c] * p0[b, c, 2l] + s0[c])                     (unet_basic.py:86 fused, p0 = raw conv out of previous level)
-//  UPCAT : c <  C0: l0*act0(p0[b,c,i0]) + l1*act0(p0[b,c,i1])      (unet_basic.py:93 F.interpolate x2, align_corners)
-//          c >= C0: lrelu(a1[c-C0] * p1[b, c-C0, l] + s1[c-C0])    (unet_basic.py:95 cat([up, skip]))
-//  GZ    : a0[c]*p0[b,c,l] + s0[c]*p1[b,c,l] + a1[c]               (BatchNorm backward folded to k1*g + k2*z + k3)
-struct SrcDesc {
-    const float* p0;
-    const float* a0;
-    const float* s0;
-    const float* p1;
-    const float* a1;
-    const float* s1;
-    int C0;        // UPCAT: channels coming from the upsampled branch; otherwise == C
-    int C;         // virtual channel count
-    int L;         // virtual length (power of two)
-    int Lsrc0;     // row length of p0 (DECIM: 2L, UPCAT: L/2, else L)
-    int logL;      // log2(L)
-    float up_scale;  // UPCAT: (float)(Lsrc0-1)/(L-1)
-};
-
-// Per-thread description of one staged LDS column: where in global memory it comes from.
-struct ColRef {
-    unsigned off0, off1;   // offsets (floats) into p0 / p1 rows for channel 0 of batch item
-    float l0, l1;          // UPCAT interpolation weights
-    unsigned offu1;        // UPCAT: second tap offset
-    unsigned out_off;      // offset of (b, channel 0, l) in a materialised [B][C][L] copy of the virtual input
-    bool valid;
-};
-
-template <int MODE>
-__device__ __forceinline__ void col_prepare(const SrcDesc& d, int b, int l, bool inb, ColRef& r)
-{
-    r.valid = inb && l >= 0 && l < d.L;
-    const int lc = r.valid ? l : 0;
-    const unsigned bb = r.valid ? (unsigned)b : 0u;
-    r.off0 = r.off1 = r.offu1 = 0;
-    r.l0 = r.l1 = 0.0f;
-    r.out_off = bb * (unsigned)d.C * (unsigned)d.L + (unsigned)lc;
-    if (MODE == SRC_RAW || MODE == SRC_GZ) {
-        r.off0 = bb * (unsigned)d.C * (unsigned)d.L + (unsigned)lc;
-        r.off1 = r.off0;
-    } else if (MODE == SRC_DECIM) {
-        r.off0 = bb * (unsigned)d.C * (unsigned)d.Lsrc0 + 2u * (unsigned)lc;
-    } else {
-        int i0, i1;
-        wunet_up_coord(lc, d.Lsrc0, d.up_scale, i0, i1, r.l0, r.l1);
-        r.off0 = bb * (unsigned)d.C0 * (unsigned)d.Lsrc0 + (unsigned)i0;
-        r.offu1 = bb * (unsigned)d.C0 * (unsigned)d.Lsrc0 + (unsigned)i1;
-        r.off1 = bb * (unsigned)(d.C - d.C0) * (unsigned)d.L + (unsigned)lc;
-    }
-}
-
-// ---- loaders.  All global loads are UNCONDITIONAL (addresses are clamped to something valid and the
-// result is selected afterwards): a per-element branch around a load makes hipcc serialise the loads
-// (one basic block and one vmcnt(0) wait per element - cdna_hip_programming.md "three .s-level traps" (c)).
-// Two-phase form for software pipelining: raw global loads now (col_fetch), arithmetic later (col_finish).
-struct RawX { float v0, v1; };
-struct ChanK { float a, s, t; };   // per-channel constants (wave-uniform): scale, shift, (GZ: k3)
-
-template <int MODE>
-__device__ __forceinline__ ChanK chan_consts(const SrcDesc& d, int c)
-{
-    ChanK k{0.f, 0.f, 0.f};
-    const int cc = c < d.C ? c : d.C - 1;
-    if (MODE == SRC_DECIM) { k.a = d.a0[cc]; k.s = d.s0[cc]; }
-    else if (MODE == SRC_GZ) { k.a = d.a0[cc]; k.s = d.s0[cc]; k.t = d.a1[cc]; }
-    else if (MODE == SRC_UPCAT) {
-        const bool up = cc < d.C0;
-        const float* pa = up ? d.a0 : d.a1;
-        const float* ps = up ? d.s0 : d.s1;
-        const int ci = up ? cc : cc - d.C0;
-        k.a = pa[ci]; k.s = ps[ci];
-    }
-    return k;
-}
-
-template <int MODE>
-__device__ __forceinline__ RawX col_fetch(const SrcDesc& d, const ColRef& r, int c)
-{
-    RawX x{0.f, 0.f};
-    const unsigned cc = (unsigned)(c < d.C ? c : d.C - 1);
-    if (MODE == SRC_RAW) {
-        x.v0 = d.p0[r.off0 + cc * (unsigned)d.L];
-    } else if (MODE == SRC_DECIM) {
-        x.v0 = d.p0[r.off0 + cc * (unsigned)d.Lsrc0];
-    } else if (MODE == SRC_GZ) {
-        const unsigned o = r.off0 + cc * (unsigned)d.L;
-        x.v0 = d.p0[o];
-        x.v1 = d.p1[o];
-    } else {
-        const bool up = cc < (unsigned)d.C0;                       // wave-uniform
-        const float* p = up ? d.p0 : d.p1;
-        const unsigned cb = up ? cc * (unsigned)d.Lsrc0 : (cc - (unsigned)d.C0) * (unsigned)d.L;
-        x.v0 = p[(up ? r.off0 : r.off1) + cb];
-        x.v1 = p[(up ? r.offu1 : r.off1) + cb];
-    }
-    return x;
-}
-
-template <int MODE>
-__device__ __forceinline__ float col_finish(const SrcDesc& d, const ColRef& r, int c, const RawX& x, const ChanK& k)
-{
-    float v;
-    if (MODE == SRC_RAW) v = x.v0;
-    else if (MODE == SRC_DECIM) v = wunet_lrelu(k.a * x.v0 + k.s);
-    else if (MODE == SRC_GZ) v = k.a * x.v0 + k.s * x.v1 + k.t;
-    else {
-        const bool up = c < d.C0;                                  // wave-uniform
-        const float w0 = up ? r.l0 : 1.0f, w1 = up ? r.l1 : 0.0f;
-        v = w0 * wunet_lrelu(k.a * x.v0 + k.s) + w1 * wunet_lrelu(k.a * x.v1 + k.s);
-    }
-    return (r.valid && c < d.C) ? v : 0.0f;
-}
-
-// value of virtual channel c at a prepared column (c is wave-uniform)
-template <int MODE>
-__device__ __forceinline__ float col_load(const SrcDesc& d, const ColRef& r, int c)
-{
-    const ChanK k = chan_consts<MODE>(d, c);
-    const RawX x = col_fetch<MODE>(d, r, c);
-    return col_finish<MODE>(d, r, c, x, k);
-}
-
-// Geometry of a position tile: TN flattened (b,l) positions = nseg segments of seg positions,
-// each segment lies inside one batch item and is staged with a halo of PAD on both sides.
-struct TileGeom {
-    int seg, seg_shift;   // seg = min(L, TN)
-    int nseg;             // TN / seg
-    int segw;             // seg + 2*PAD
-    int rowlen;           // staged columns per channel row
-    int rowp;             // LDS row stride (floats)
-    unsigned segw_magic;  // ceil(2^20 / segw)
-};
-
-// column index -> (batch item, sample index incl. halo) for a tile starting at flattened position n0
-__device__ __forceinline__ void col_to_bl(const TileGeom& g, int logL, int L, int n0, int col, int pad, int& b, int& l)
-{
-    const int sg = (int)(((unsigned)col * g.segw_magic) >> 20);
-    const int w = col - sg * g.segw - pad;
-    const int gpos = n0 + (sg << g.seg_shift);
-    b = gpos >> logL;
-    l = (gpos & (L - 1)) + w;
-}
-
+// A position tile of TN flattened (b,l) positions = nseg segments of seg = min(L, TN) positions; every
+// segment lies inside one batch item and is staged as seg+16 floats (halo of 8 left and right).
 struct ConvArgs {
-    SrcDesc src;
-    TileGeom geo;
+    const float* x;     // [B][Cin][L] materialised input (zero padding is implied by the bounds)
     const float* wpk;   // packed weights [Mtiles_padded][CinP][TAPS][16]
     const float* bias;  // [Cout] or nullptr
-    float* out;         // [B][Cout][L]
+    float* out;         // [B][Cout][L]  (+ z-slice * split_stride when split-K)
     float* stats;       // nullptr or [gridDim.x*4][Cout][2]  (sum, sum of squares of the bias-free conv)
-    int B, Cout, CinP;
-    float* xout;           // nullptr or [B][C][L]: the staged (activated / g_z) input tile is also written here by
-                           // the blockIdx.y == 0 blocks, so the weight-gradient GEMM reads it instead of re-deriving it
+    int B, Cin, Cout, CinP, L, logL;
+    int seg, seg_shift, segw;      // segw = seg + 16
+    int rowp;                      // LDS row stride
+    int r4, sw4;                   // float4 per staged row / per segment
+    unsigned r4_magic, sw4_magic;  // ceil(2^20 / r4), ceil(2^20 / sw4)
     int kc_per_split;      // split-K over gridDim.z: padded input channels per z-slice (== CinP when unsplit)
     size_t split_stride;   // floats between the partial outputs of consecutive z-slices
 };
 
-template <int TAPS, int MODE, int M_REP, int N_REP>
+template <int TAPS, int M_REP, int N_REP>
 __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
 {
     constexpr int PAD = TAPS / 2;
     constexpr int KC = (TAPS == 15) ? 4 : 12;
+    constexpr int XIT = (TAPS == 15) ? 2 : 4;       // float4 x slots per thread: KC * r4 <= 256 * XIT
     constexpr int TN = 64 * N_REP;
-    constexpr int WCHUNK = KC * TAPS * 16;   // floats of one m-tile's K-chunk
+    constexpr int WCHUNK = KC * TAPS * 16;          // floats of one m-tile's K-chunk (240 float4)
     WUNET_DYN_SMEM(smem);
-    float* xs = smem;
-    float* ws = smem + KC * A.geo.rowp;
+    float* xs = smem;                               // [KC][rowp]
+    float* ws = smem + KC * A.rowp;                 // [M_REP][KC][TAPS][16]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
     const int n0 = blockIdx.x * TN;
     const int mt0 = blockIdx.y * M_REP;
-    const SrcDesc& S = A.src;
-    const int L = S.L;
+    const int L = A.L;
 
-    // columns this thread stages (same for every K-chunk)
-    ColRef cr[2];
+    // ---- per-thread x staging slots (the tile is fixed for the block, only the channel chunk moves)
+    int xrow[XIT], xlds[XIT];
+    unsigned xg[XIT];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int col = tid + it * WUNET_THREADS;
-        int b, l;
-        col_to_bl(A.geo, S.logL, L, n0, col, PAD, b, l);
-        col_prepare<MODE>(S, b, l, col < A.geo.rowlen && b < A.B, cr[it]);
-    }
-
-    // columns that are tile interior (not halo) are also materialised to xout
-    bool xw[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int col = tid + it * WUNET_THREADS;
-        const int sg = (int)(((unsigned)col * A.geo.segw_magic) >> 20);
-        const int w = col - sg * A.geo.segw - PAD;
-        xw[it] = A.xout != nullptr && blockIdx.y == 0 && cr[it].valid && w >= 0 && w < A.geo.seg && col < A.geo.rowlen;
+    for (int it = 0; it < XIT; ++it) {
+        const int f = tid + it * WUNET_THREADS;
+        const int row = (int)(((unsigned)f * A.r4_magic) >> 20);
+        const int c4 = f - row * A.r4;
+        const int sg = (int)(((unsigned)c4 * A.sw4_magic) >> 20);
+        const int w4 = c4 - sg * A.sw4;
+        const int gpos = n0 + (sg << A.seg_shift);
+        const int b = gpos >> A.logL, l = (gpos & (L - 1)) + 4 * w4 - 8;
+        const bool ok = row < KC && b < A.B && l >= 0 && l < L;
+        xrow[it] = ok ? row : -1 - (row < KC ? row : KC);     // < 0: zero fill (still a valid LDS slot when row < KC)
+        xlds[it] = row * A.rowp + sg * A.segw + 4 * w4;
+        xg[it] = ok ? (unsigned)b * (unsigned)A.Cin * (unsigned)L + (unsigned)l : 0u;
     }
 
     int xoff[N_REP];
 #pragma unroll
     for (int nt = 0; nt < N_REP; ++nt) {
         const int tp = wave * 16 * N_REP + nt * 16 + i16;
-        const int sg = tp >> A.geo.seg_shift;
-        xoff[nt] = q * A.geo.rowp + sg * A.geo.segw + (tp & (A.geo.seg - 1));
+        const int sg = tp >> A.seg_shift;
+        xoff[nt] = q * A.rowp + sg * A.segw + (tp & (A.seg - 1)) + (8 - PAD);
     }
     const int aoff = q * TAPS * 16 + i16;
 
@@ -236,37 +95,28 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
     float* const outp = A.out + (size_t)blockIdx.z * A.split_stride;
 
     // software pipeline: the global loads of chunk k+1 are in flight while chunk k runs on the matrix cores
-    RawX rx[KC][2];
-    ChanK ck[KC];
-    float4 wreg[M_REP];
+    wunet_f4 xreg[XIT], wreg[M_REP];
     const int wtid = tid < WCHUNK / 4 ? tid : 0;      // clamped: threads >= WCHUNK/4 load a dummy, never store it
 #define WUNET_PREFETCH(C0_)                                                                                     \
     {                                                                                                           \
-        _Pragma("unroll") for (int cl = 0; cl < KC; ++cl) {                                                     \
-            ck[cl] = chan_consts<MODE>(S, (C0_) + cl);                                                          \
-            _Pragma("unroll") for (int it = 0; it < 2; ++it) rx[cl][it] = col_fetch<MODE>(S, cr[it], (C0_) + cl); \
+        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                    \
+            const int c_ = (C0_) + (xrow[it] >= 0 ? xrow[it] : 0);                                              \
+            const bool ok_ = xrow[it] >= 0 && c_ < A.Cin;                                                       \
+            xreg[it] = wunet_sel4(ok_, wunet_ld4(A.x + (ok_ ? xg[it] + (unsigned)c_ * (unsigned)L : 0u)));       \
         }                                                                                                       \
         _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                    \
-            wreg[mt] = reinterpret_cast<const float4*>(A.wpk + ((size_t)(mt0 + mt) * A.CinP + (C0_)) * (TAPS * 16))[wtid]; \
+            wreg[mt] = wunet_ld4(A.wpk + ((size_t)(mt0 + mt) * A.CinP + (C0_)) * (TAPS * 16) + 4 * wtid);      \
     }
     WUNET_PREFETCH(cbeg)
 
     for (int c0 = cbeg; c0 < cend; c0 += KC) {
         __syncthreads();      // every wave is done reading the previous chunk from LDS
-        // ---- registers -> LDS (BN scale/shift, LeakyReLU, interpolation applied here)
 #pragma unroll
-        for (int cl = 0; cl < KC; ++cl) {
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {
-                const int col = tid + it * WUNET_THREADS;
-                const float xv = col_finish<MODE>(S, cr[it], c0 + cl, rx[cl][it], ck[cl]);
-                if (col < A.geo.rowlen) xs[cl * A.geo.rowp + col] = xv;
-                if (xw[it] && c0 + cl < S.C) A.xout[cr[it].out_off + (unsigned)(c0 + cl) * (unsigned)L] = xv;
-            }
-        }
+        for (int it = 0; it < XIT; ++it)
+            if (xrow[it] > -1 - KC) wunet_st4(xs + xlds[it], xreg[it]);
         if (tid < WCHUNK / 4) {
 #pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt) reinterpret_cast<float4*>(ws + mt * WCHUNK)[tid] = wreg[mt];
+            for (int mt = 0; mt < M_REP; ++mt) wunet_st4(ws + mt * WCHUNK + 4 * tid, wreg[mt]);
         }
         __syncthreads();
         if (c0 + KC < cend) WUNET_PREFETCH(c0 + KC)
@@ -279,7 +129,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
 #pragma unroll
                 for (int mt = 0; mt < M_REP; ++mt) af[mt] = ws[(mt * KC + 4 * s) * TAPS * 16 + tap * 16 + aoff];
 #pragma unroll
-                for (int nt = 0; nt < N_REP; ++nt) bf[nt] = xs[4 * s * A.geo.rowp + tap + xoff[nt]];
+                for (int nt = 0; nt < N_REP; ++nt) bf[nt] = xs[4 * s * A.rowp + tap + xoff[nt]];
 #pragma unroll
                 for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
@@ -287,8 +137,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
             }
         }
     }
-
 #undef WUNET_PREFETCH
+
     // ---- epilogue: bias, store, per-channel partial statistics of the bias-free conv
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
@@ -296,7 +146,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
 #pragma unroll
         for (int nt = 0; nt < N_REP; ++nt) {
             const int n = n0 + wave * 16 * N_REP + nt * 16 + i16;
-            const int b = n >> S.logL, l = n & (L - 1);
+            const int b = n >> A.logL, l = n & (L - 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
@@ -338,14 +188,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
 //   WSPLIT (Cin < 4 n-tiles, i.e. encoder[0]): all four waves work on n-tile 0 and split the K-steps;
 //   each wave writes its own partial row.
 //   Partials part[row][Cout][Cin][TAPS] are summed by wgrad_reduce_kernel in a fixed order (deterministic).
-// component-wise select (a struct-level ?: on float4 goes through scratch memory with hipcc)
-__device__ __forceinline__ float4 wunet_sel4(bool ok, const float4& v)
-{
-    float4 r;
-    r.x = ok ? v.x : 0.0f; r.y = ok ? v.y : 0.0f; r.z = ok ? v.z : 0.0f; r.w = ok ? v.w : 0.0f;
-    return r;
-}
-
 struct WgradArgs {
     const float* x;      // [B][Cin][L]
     const float* g;      // [B][Cout][L]
@@ -412,7 +254,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
 #pragma unroll
         for (int k = 0; k < NW; ++k) acc[mt][k] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
-    float4 greg[M_REP], xreg[XIT];
+    wunet_f4 greg[M_REP], xreg[XIT];
 #define WUNET_WG_PREFETCH(P0_)                                                                                   \
     {                                                                                                            \
         const int p_ = (P0_) + 4 * gq;                                                                           \
@@ -421,8 +263,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
             const int co_ = co0 + (tid >> 4) + 16 * it;                                                          \
             const bool ok_ = b_ < A.B && co_ < A.Cout;                                                           \
             const size_t o_ = ok_ ? ((size_t)b_ * A.Cout + co_) * L + l_ : 0;                                    \
-            const float4 v_ = *reinterpret_cast<const float4*>(A.g + o_);                                        \
-            greg[it] = wunet_sel4(ok_, v_);                                                                      \
+            greg[it] = wunet_sel4(ok_, wunet_ld4(A.g + o_));                                                     \
         }                                                                                                        \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                     \
             const int gp_ = (P0_) + (xsg[it] << A.seg_shift);                                                    \
@@ -430,8 +271,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
             const int ci_ = ci0 + xrow[it];                                                                      \
             const bool ok_ = xrow[it] >= 0 && ci_ < A.Cin && xb_ < A.B && xl_ >= 0 && xl_ < L;                   \
             const size_t o_ = ok_ ? ((size_t)xb_ * A.Cin + ci_) * L + xl_ : 0;                                   \
-            const float4 v_ = *reinterpret_cast<const float4*>(A.x + o_);                                        \
-            xreg[it] = wunet_sel4(ok_, v_);                                                                      \
+            xreg[it] = wunet_sel4(ok_, wunet_ld4(A.x + o_));                                                     \
         }                                                                                                        \
     }
     const int pbeg = split * A.chunks_per_split * TP;
@@ -443,12 +283,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
 #pragma unroll
         for (int it = 0; it < M_REP; ++it) {
             float* dst = gs + ((tid >> 4) + 16 * it) * GROW + 4 * gq;      // 8-byte aligned
-            reinterpret_cast<float2*>(dst)[0] = float2{greg[it].x, greg[it].y};
-            reinterpret_cast<float2*>(dst)[1] = float2{greg[it].z, greg[it].w};
+            reinterpret_cast<float2*>(dst)[0] = float2{greg[it][0], greg[it][1]};
+            reinterpret_cast<float2*>(dst)[1] = float2{greg[it][2], greg[it][3]};
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it)
-            if (xrow[it] >= 0) *reinterpret_cast<float4*>(xs + xlds[it]) = xreg[it];
+            if (xrow[it] >= 0) wunet_st4(xs + xlds[it], xreg[it]);
         __syncthreads();
         if (ch + 1 < A.chunks_per_split) WUNET_WG_PREFETCH(pbeg + (ch + 1) * TP)
 #pragma unroll 4

@@ -8,15 +8,11 @@
 #define WUNET_LAUNCH(kern, grid, block, smem, stream, ...) hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
 #endif
 
-// One translation unit per (taps, loader mode) keeps hipcc builds parallel.  Return 0 when a kernel
+// One translation unit per tap count keeps hipcc builds parallel.  Return 0 when a kernel
 // for (mrep, nrep) exists and was enqueued, -1 otherwise.
-#define WUNET_DECL_CONV(T, M) int wunet_launch_conv_##T##_##M(const ConvArgs& a, int mrep, int nrep, dim3 grid, size_t smem, hipStream_t st)
+#define WUNET_DECL_CONV(T) int wunet_launch_conv_##T(const ConvArgs& a, int mrep, int nrep, dim3 grid, size_t smem, hipStream_t st)
 #define WUNET_DECL_WGRAD(T) int wunet_launch_wgrad_##T(const WgradArgs& a, int mrep, int nw, int xit, int wsplit, dim3 grid, size_t smem, hipStream_t st)
-WUNET_DECL_CONV(15, 0);
-WUNET_DECL_CONV(15, 1);
-WUNET_DECL_CONV(5, 2);
-WUNET_DECL_CONV(15, 3);
-WUNET_DECL_CONV(5, 3);
-WUNET_DECL_CONV(5, 0);
+WUNET_DECL_CONV(15);
+WUNET_DECL_CONV(5);
 WUNET_DECL_WGRAD(15);
 WUNET_DECL_WGRAD(5);
