@@ -1,0 +1,106 @@
+"""world_size=2 gloo tests (CPU) of the data-parallel path: parallel.GradSync buckets the flat
+gradient buffer in backward order, all-reduces each finished bucket and averages - and the result
+equals the average of the per-shard oracle gradients with per-shard BatchNorm (the DataParallel
+semantics of the reference, trainer/base_trainer.py:26-27)."""
+import importlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PKG_NAME, ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bucket_ranges_cover_everything_in_backward_order():
+    parallel = importlib.import_module(PKG_NAME + ".parallel")
+    plan = importlib.import_module(PKG_NAME + ".plan")
+    n, ci = 12, 24
+    numels = []
+    for c_in, c_out, k in plan.conv_layer_shapes(n, ci):
+        numels += [c_out * c_in * k, c_out, c_out, c_out]
+    numels += [ci + 1, 1]
+    nl = 2 * n + 1
+    for nb in (1, 2, 4, 7):
+        ranges = parallel.bucket_ranges(numels, nl, nb)
+        assert 1 <= len(ranges) <= nb
+        assert ranges[0][1] == nl and ranges[-1][0] == 0           # starts at the head, ends at encoder[0]
+        for (lb, le, fb, fe), nxt in zip(ranges, ranges[1:] + [None]):
+            assert lb < le and fb < fe
+            if nxt is not None:
+                assert nxt[1] == lb and nxt[3] == fb                  # contiguous, walking backwards
+        assert ranges[-1][2] == 0 and ranges[0][3] == sum(numels)    # whole flat buffer, head params included
+        if nb == 4:
+            sizes = [fe - fb for _, _, fb, fe in ranges]
+            assert max(sizes) < 0.6 * sum(numels)                    # balanced enough to overlap
+
+
+def _worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import emu_lib
+        from oracle import plan
+        eng_mod = importlib.import_module(PKG_NAME + ".engine")
+        lib_mod = importlib.import_module(PKG_NAME + "._lib")
+        model_mod = importlib.import_module(PKG_NAME + ".model")
+        loss_mod = importlib.import_module(PKG_NAME + ".loss")
+        parallel = importlib.import_module(PKG_NAME + ".parallel")
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+        n, ci, B, T = 3, 8, 2, 64
+        sd = plan.golden_state(n, ci, 0)
+        m = model_mod.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        m._engine_override = eng
+        m.grad_sync = parallel.GradSync(n_buckets=3)
+        noisy, clean = plan.golden_batch(B * world, T, 0)
+        sl = slice(rank * B, (rank + 1) * B)                          # this rank's shard of the global batch
+        crit = loss_mod.mse_loss()
+        crit._engine_override = eng
+        m.train()
+        out = m(torch.from_numpy(noisy[sl].copy()))
+        crit(torch.from_numpy(clean[sl].copy()), out).backward()
+        grads = {k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+        np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), **grads)
+        # every rank must hold identical (averaged) gradients
+        flat = m.last_flat_grad.clone()
+        ref = flat.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(flat, ref)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_sync_matches_average_of_shard_oracles(tmp_path):
+    from oracle import c_oracle, plan
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    n, ci, B, T = 3, 8, 2, 64
+    noisy, clean = plan.golden_batch(B * world, T, 0)
+    refs = []
+    for r in range(world):
+        sd = plan.golden_state(n, ci, 0)
+        refs.append(c_oracle.step(sd, noisy[r * B:(r + 1) * B], clean[r * B:(r + 1) * B], n, ci, True, "mse")["grads"])
+    got = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    got1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    for k in refs[0]:
+        avg = (refs[0][k].astype(np.float64) + refs[1][k].astype(np.float64)) / 2
+        assert np.array_equal(got[k], got1[k]), k
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            assert np.all(got[k] == 0.0)
+            continue
+        scale = max(np.abs(avg).max(), 1e-6)
+        assert np.abs(got[k] - avg).max() < 3e-4 * scale + 1e-6, (k, np.abs(got[k] - avg).max(), scale)
