@@ -100,5 +100,14 @@ inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::m
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
 inline hipError_t hipGetLastError() { return 0; }
+#define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)1; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }

@@ -268,8 +268,12 @@ struct wunet_ctx {
     int n, ci, B, T, NL;
     std::vector<LayerPlan> ly;
     size_t stats_off, wpkf_off, spart_off, fwd_floats;
-    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, gz_off, total_floats;
+    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
     int head_blocks;
+    // side stream for the weight-gradient GEMMs (off the backward's critical chain), created lazily per device
+    int side_dev = -1;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 extern "C" {
@@ -330,7 +334,7 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
     c->spart_off = off; off += align64(spart_max);
     c->fwd_floats = off;
 
-    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0, gz_max = 0;
+    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
         l.g = off; off += align64((size_t)B * l.cout * l.L);
@@ -340,7 +344,6 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         l.k3 = off; off += align64(l.cout);
         l.d_wpk = wpkb;
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
-        if ((size_t)B * l.cout * l.L > gz_max) gz_max = (size_t)B * l.cout * l.L;
         const size_t wg = (size_t)l.w.rows * l.cout * l.cin * l.taps;
         if (wg > wgpart_max) wgpart_max = wg;
         long long sp = ((long long)B * l.L) / 4096;
@@ -356,13 +359,17 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         c->head_blocks = (int)(hb < 1 ? 1 : (hb > 1024 ? 1024 : hb));
     }
     c->hpart_off = off; off += align64((size_t)c->head_blocks * (ci + 2));
-    c->gz_off = off; off += align64(gz_max);
     c->total_floats = off;
     *out = c;
     return WUNET_OK;
 }
 
-void wunet_destroy(wunet_ctx* ctx) { delete ctx; }
+void wunet_destroy(wunet_ctx* ctx)
+{
+    if (!ctx) return;
+    if (ctx->side) { hipStreamDestroy(ctx->side); hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join); }
+    delete ctx;
+}
 
 size_t wunet_workspace_bytes(const wunet_ctx* ctx, int with_backward)
 {
@@ -480,6 +487,21 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const int NL = c->NL, n = c->n;
+    // weight gradients run on a side stream: they only depend on g_z and x of their own layer, so the HBM-bound
+    // gradient-assembly kernels of the next layers overlap with them instead of idling the matrix cores
+    {
+        int dev = 0;
+        hipGetDevice(&dev);
+        if (c->side_dev != dev) {
+            if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); c->side = nullptr; }
+            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+                return fail(WUNET_E_RUNTIME, "cannot create the side stream");
+            c->side_dev = dev;
+        }
+    }
+    hipStream_t sd = g_prof_on ? st : c->side;      // the per-kernel profiler serialises everything on one stream
 
     if (layer_end == NL) {
         // flipped/transposed weights for every data gradient (one launch)
@@ -543,14 +565,33 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
             WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + c->gz_off);
+                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
+            WUNET_CHECK_LAUNCH();
+        }
+        // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
+        //      + deterministic reduce
+        {
+            if (sd != st) {
+                hipEventRecord(c->ev_fork, st);
+                hipStreamWaitEvent(sd, c->ev_fork, 0);
+            }
+            const float* xin = i == 0 ? noisy : ws + l.xin;
+            const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
+            int rc = launch_wgrad_any(l.taps, w, l.w, sd);
+            if (rc) return rc;
+            WUNET_CHECK_LAUNCH();
+            const size_t nw = (size_t)l.cout * l.cin * l.taps;
+            size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
+            if (blocks > 2048) blocks = 2048;
+            WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
+                         (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
             WUNET_CHECK_LAUNCH();
         }
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
         if (i > 0) {
             const bool split = l.d.ksplit > 1;
             const size_t nd = (size_t)c->B * l.cin * l.L;
-            const ConvArgs a = make_conv_args(ws + c->gz_off, l.cout, ws + c->wpkb_off + l.d_wpk, nullptr,
+            const ConvArgs a = make_conv_args(ws + l.g, l.cout, ws + c->wpkb_off + l.d_wpk, nullptr,
                                               split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.L, l.taps, l.d, nd);
             int rc = launch_conv(l.taps, "dgrad", a, l.d, st);
             if (rc) return rc;
@@ -562,20 +603,10 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 WUNET_CHECK_LAUNCH();
             }
         }
-        // ---- weight gradient: GEMM over positions on the materialised operands, split-K partials + deterministic reduce
-        {
-            const float* xin = i == 0 ? noisy : ws + l.xin;
-            const WgradArgs w = make_wgrad_args(xin, ws + c->gz_off, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
-            int rc = launch_wgrad_any(l.taps, w, l.w, st);
-            if (rc) return rc;
-            WUNET_CHECK_LAUNCH();
-            const size_t nw = (size_t)l.cout * l.cin * l.taps;
-            size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
-            if (blocks > 2048) blocks = 2048;
-            WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st,
-                         (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
-            WUNET_CHECK_LAUNCH();
-        }
+    }
+    if (sd != st) {          // join: the caller's stream sees every gradient
+        hipEventRecord(c->ev_join, sd);
+        hipStreamWaitEvent(st, c->ev_join, 0);
     }
     return WUNET_OK;
 }

@@ -295,43 +295,69 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x;
-    const size_t total = (size_t)A.B * A.L;
-    const size_t per = (total + gridDim.y - 1) / gridDim.y;
-    const size_t beg = (size_t)blockIdx.y * per, end = beg + per < total ? beg + per : total;
+    // each thread produces four consecutive samples (aligned float4 traffic); L is a power of two >= 4
+    const size_t total4 = ((size_t)A.B * A.L) >> 2;
+    const size_t per = (total4 + gridDim.y - 1) / gridDim.y;
+    const size_t beg = (size_t)blockIdx.y * per, end = beg + per < total4 ? beg + per : total4;
     const float a = A.a[c], s = A.s[c], mu = A.mean[c], rstd = A.rstd[c];
     const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
     double s1 = 0.0, s2 = 0.0;
-    for (size_t p = beg + threadIdx.x; p < end; p += WUNET_THREADS) {
+    for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += WUNET_THREADS) {
+        const size_t p = q4 << 2;
         const int b = (int)(p >> A.logL), l = (int)(p & (size_t)(A.L - 1));
         const size_t zi = ((size_t)b * A.C + c) * A.L + l;
-        const float z = A.z[zi];
-        float g;
+        const wunet_f4 z = wunet_ld4(A.z + zi);
+        float g[4];
         if (MODE == A_HEAD) {
-            g = wh * A.g0[(size_t)b * A.L + l];
+            const wunet_f4 gh = wunet_ld4(A.g0 + (size_t)b * A.L + l);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) g[j] = wh * gh[j];
         } else if (MODE == A_ENC) {
-            g = A.g0[((size_t)b * A.Cg0 + A.coff + c) * A.L + l];
-            if ((l & 1) == 0) g += A.g1[((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1)];
+            const wunet_f4 gd = wunet_ld4(A.g0 + ((size_t)b * A.Cg0 + A.coff + c) * A.L + l);
+            const float* ge = A.g1 + ((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1);
+            g[0] = gd[0] + ge[0]; g[1] = gd[1]; g[2] = gd[2] + ge[1]; g[3] = gd[3];
         } else {
-            // transpose of ATen's upsample_linear1d: every output j in [2l-2, 2l+2] whose fp32-computed
-            // source indices hit l contributes (ascending j, same order as ATen's backward loop)
+            // transpose of ATen's upsample_linear1d: output j contributes l0 to input i0(j) and l1 to i1(j), with the
+            // fp32-computed coordinates; inputs l..l+3 can only be hit by outputs j in [2l-2, 2l+8], walked in
+            // ascending j like ATen's backward loop
             const int Lo = 2 * A.L;
             const float* row = A.g0 + ((size_t)b * A.Cg0 + c) * Lo;
-            g = 0.0f;
+            float d[12];
+            const int j0 = 2 * l - 4;                         // 16-byte aligned
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int j = 2 * l - 2 + k;
+            for (int v = 0; v < 3; ++v) {
+                const int jv = j0 + 4 * v;
+                const bool ok = jv >= 0 && jv < Lo;
+                const wunet_f4 t = wunet_sel4(ok, wunet_ld4(row + (ok ? jv : 0)));
+                d[4 * v] = t[0]; d[4 * v + 1] = t[1]; d[4 * v + 2] = t[2]; d[4 * v + 3] = t[3];
+            }
+            const float dlast = (j0 + 12 < Lo) ? row[j0 + 12] : 0.0f;
+            g[0] = g[1] = g[2] = g[3] = 0.0f;
+#pragma unroll
+            for (int k = 2; k <= 12; ++k) {                   // j = 2l-2 .. 2l+8
+                const int j = j0 + k;
+                const float dv = k < 12 ? d[k < 12 ? k : 0] : dlast;
                 if (j >= 0 && j < Lo) {
                     int i0, i1; float l0, l1;
                     wunet_up_coord(j, A.L, A.up_scale, i0, i1, l0, l1);
-                    const float w = (i0 == l ? l0 : 0.0f) + (i1 == l ? l1 : 0.0f);
-                    if (w != 0.0f) g += w * row[j];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float w = (i0 == l + m ? l0 : 0.0f) + (i1 == l + m ? l1 : 0.0f);
+                        g[m] += w * dv;
+                    }
                 }
             }
         }
-        if (!(a * z + s > 0.0f)) g *= WUNET_SLOPE;
-        A.gpre[zi] = g;
-        s1 += (double)g;
-        s2 += (double)(g * ((z - mu) * rstd));
+        wunet_f4 go;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gv = g[j];
+            if (!(a * z[j] + s > 0.0f)) gv *= WUNET_SLOPE;
+            go[j] = gv;
+            s1 += (double)gv;
+            s2 += (double)(gv * ((z[j] - mu) * rstd));
+        }
+        wunet_st4(A.gpre + zi, go);
     }
     block_sum2(s1, s2, red);
     if (threadIdx.x == 0) {
@@ -379,18 +405,32 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArg
 // ---------------------------------------------------------------------------- split-K reduce of dW
 __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float* part, int splits, size_t n, float* dw)
 {
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
-        float s = 0.0f;
+    // fixed order (deterministic): groups of 8 rows in fp32, groups in fp64.  n is a multiple of 4 for every conv
+    // of this net (taps * Cin * Cout with Cout a multiple of 4 or taps*Cin...), otherwise the scalar tail handles it.
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
         int r = 0;
-        // pairwise-ish: sum groups of 8 in fp32, groups in double (deterministic, fixed order)
-        double tot = 0.0;
         for (; r + 8 <= splits; r += 8) {
-            s = 0.0f;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) s += part[(size_t)(r + k) * n + i];
-            tot += (double)s;
+            for (int k = 0; k < 8; ++k) {
+                const wunet_f4 v = wunet_ld4(part + (size_t)(r + k) * n + 4 * i);
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            }
+            t0 += (double)a0; t1 += (double)a1; t2 += (double)a2; t3 += (double)a3;
         }
-        for (; r < splits; ++r) tot += (double)part[(size_t)r * n + i];
+        for (; r < splits; ++r) {
+            const wunet_f4 v = wunet_ld4(part + (size_t)r * n + 4 * i);
+            t0 += (double)v[0]; t1 += (double)v[1]; t2 += (double)v[2]; t3 += (double)v[3];
+        }
+        wunet_f4 o;
+        o[0] = (float)t0; o[1] = (float)t1; o[2] = (float)t2; o[3] = (float)t3;
+        wunet_st4(dw + 4 * i, o);
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
+        double tot = 0.0;
+        for (int r = 0; r < splits; ++r) tot += (double)part[(size_t)r * n + i];
         dw[i] = (float)tot;
     }
 }
