@@ -6,6 +6,7 @@
 #define WUNET_CAT(a) WUNET_CAT2(a, )
 #define WUNET_CASE(M, N)                                                                                       \
     if (mrep == M && nrep == N) {                                                                              \
+        if (WUNET_ALLOW_BIG_LDS((conv_mfma_kernel<WUNET_INST_TAPS, M, N>), smem) != 0) return -2;              \
         WUNET_LAUNCH((conv_mfma_kernel<WUNET_INST_TAPS, M, N>), grid, dim3(WUNET_THREADS), smem, st, a);       \
         return 0;                                                                                              \
     }

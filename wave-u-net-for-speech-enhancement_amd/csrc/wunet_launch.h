@@ -4,8 +4,12 @@
 
 #ifdef WUNET_EMU
 #define WUNET_LAUNCH(kern, grid, block, smem, stream, ...) emu::launch(grid, block, smem, [=]() { kern(__VA_ARGS__); })
+#define WUNET_ALLOW_BIG_LDS(kern, smem) 0
 #else
 #define WUNET_LAUNCH(kern, grid, block, smem, stream, ...) hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
+// gfx950 has 160 KiB of LDS per CU; more than 64 KiB of dynamic LDS must be requested per kernel
+#define WUNET_ALLOW_BIG_LDS(kern, smem) \
+    ((smem) > 64 * 1024 ? (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)) : 0)
 #endif
 
 // One translation unit per tap count keeps hipcc builds parallel.  Return 0 when a kernel
