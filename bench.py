@@ -168,8 +168,19 @@ def main():
             avg_ms = top["ms"] / top["launches"]
             achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
             mfma_ms = sum(r["ms"] for r in rows) / nprof
+            # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
+            traffic, traffic_src = None, None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+                if top["kernel"] in pmc["kernels"]:
+                    traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
+                    traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
+            except (OSError, ValueError, KeyError):
+                pass
             roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                        "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                        "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                         "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                         "mfma_kernels_ms_per_step": mfma_ms,
                         "all_mfma_kernels_achieved": sum(r["flops"] for r in rows) / nprof / (mfma_ms * 1e-3) / 1e12,
