@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU (weak scaling)")
+    ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam (f1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -111,7 +112,9 @@ def main():
     torch.manual_seed(0)                         # same init on every rank (reference train.py:12)
     model = pkg.Model(n_layers=N_LAYERS, channels_interval=CI).to(device).train()
     crit = pkg.smooth_l1_loss()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.999))     # reference train.py:31-35
+    optim_mod = importlib.import_module(PKG + ".optim")
+    adam_cls = torch.optim.Adam if args.torch_adam else optim_mod.FusedAdam     # reference train.py:31-35
+    opt = adam_cls(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     if world > 1:
         model.grad_sync = parallel.GradSync(n_buckets=4)
     noisy, clean = synthetic_batch(args.batch, device, seed=rank)
@@ -203,7 +206,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"unet_basic 12-level, {FRAME}-sample frames, batch={args.batch} per GPU, fp32, "
-                                   "training-mode forward + smooth_l1 + backward + Adam step "
+                                   "training-mode forward + smooth_l1 + backward + " + ("torch.optim.Adam" if args.torch_adam else "fused HIP Adam") + " step "
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",
                        "global_batch": args.batch * world, "frame": FRAME,
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},

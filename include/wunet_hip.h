@@ -79,6 +79,13 @@ int wunet_loss_forward(int kind, const float* clean, const float* enhanced, size
 int wunet_loss_backward(int kind, const float* clean, const float* enhanced, const float* grad_loss,
                         size_t n, float* grad_enhanced, void* stream);
 
+/* replaces optimizer.step() of torch.optim.Adam(params, lr, betas) as the reference builds it
+ * (train.py:31-35; eps, weight_decay=0, amsgrad=False fixed by the reference's call) for n_tensors tensors in one
+ * or two launches.  step is the 1-based step count AFTER the increment (torch's state["step"]).  numels: host array. */
+int wunet_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const size_t* numels, double lr, double beta1, double beta2, double eps,
+                    long long step, void* stream);
+
 /* Introspection for tests / profiling: float offset of layer i's raw conv output inside the
  * workspace, its channel count and length. */
 int wunet_layer_info(const wunet_ctx* ctx, int layer, size_t* z_offset_floats, int* channels, int* length);

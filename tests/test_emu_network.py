@@ -68,3 +68,29 @@ def test_eval_forward_matches_oracle(emu_engine):
     before = plan.golden_state(n, ci, 0)
     for k in plan.buffer_names(n, ci):
         assert np.array_equal(m.state_dict()[k].numpy(), before[k]), k
+
+
+def test_fused_adam_matches_torch(emu_engine):
+    """the fused Adam launch against torch.optim.Adam (train.py:31-35), three steps."""
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    torch.manual_seed(0)
+    shapes = [(7, 3, 15), (7,), (33,), (1, 5, 1), (300,)]
+    ref_p = [torch.randn(s, requires_grad=True) for s in shapes]
+    our_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-3, betas=(0.9, 0.999))
+    ours = optim_mod.FusedAdam(our_p, lr=1e-3, betas=(0.9, 0.999))
+    ours._engine_override = emu_engine
+    for it in range(3):
+        for a, b in zip(ref_p, our_p):
+            g = torch.randn_like(a) * (10.0 ** (it - 1))
+            a.grad = g.clone()
+            b.grad = g.clone()
+        ref.step()
+        ours.step()
+        for a, b in zip(ref_p, our_p):
+            assert (a - b).abs().max().item() < 2e-7, it
+    sd_ref, sd_our = ref.state_dict(), ours.state_dict()
+    assert sd_ref["state"].keys() == sd_our["state"].keys()
+    for k in sd_ref["state"]:
+        assert set(sd_ref["state"][k].keys()) == set(sd_our["state"][k].keys())
+        assert (sd_ref["state"][k]["exp_avg_sq"] - sd_our["state"][k]["exp_avg_sq"]).abs().max().item() < 1e-7

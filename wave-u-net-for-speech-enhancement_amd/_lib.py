@@ -14,6 +14,7 @@ EXPORTS = [
     "wunet_backward", "wunet_backward_range", "wunet_loss_scratch_bytes", "wunet_loss_forward",
     "wunet_loss_backward", "wunet_layer_info", "wunet_num_conv_layers", "wunet_op_conv1d",
     "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
+    "wunet_adam_step",
 ]
 
 _vp = ctypes.c_void_p
@@ -43,6 +44,8 @@ def declare(lib):
         getattr(lib, name).argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_op_conv1d_dgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_op_conv1d_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    lib.wunet_adam_step.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_longlong, _vp]
     lib.wunet_profile_enable.argtypes = [_i]
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
     lib.wunet_profile_collect.restype = ctypes.c_longlong

@@ -2,6 +2,7 @@
 // C ABI declared in include/wunet_hip.h.  No torch types, no hidden device allocations on the hot
 // path (the caller owns the workspace), nothing synchronises the stream.
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -646,6 +647,36 @@ int wunet_loss_backward(int kind, const float* clean, const float* enhanced, con
     if (blocks > 2048) blocks = 2048;
     WUNET_LAUNCH(loss_bwd_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, kind, clean, enhanced, grad_loss, n, grad_enhanced);
     WUNET_CHECK_LAUNCH();
+    return WUNET_OK;
+}
+
+// ---------------------------------------------------------------------------- fused Adam
+int wunet_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                    float* const* exp_avg_sq, const size_t* numels, double lr, double beta1, double beta2, double eps,
+                    long long step, void* stream)
+{
+    if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numels))) return fail(WUNET_E_ARG, "null argument");
+    if (step < 1) return fail(WUNET_E_ARG, "step must be >= 1");
+    hipStream_t st = (hipStream_t)stream;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    for (int base = 0; base < n_tensors; base += WUNET_ADAM_MAX) {
+        AdamTable T{};
+        const int cnt = n_tensors - base < WUNET_ADAM_MAX ? n_tensors - base : WUNET_ADAM_MAX;
+        size_t nmax = 0;
+        for (int k = 0; k < cnt; ++k) {
+            if (numels[base + k] >= (1ull << 32)) return fail(WUNET_E_ARG, "tensor too large");
+            T.p[k] = params[base + k]; T.g[k] = grads[base + k]; T.m[k] = exp_avg[base + k]; T.v[k] = exp_avg_sq[base + k];
+            T.n[k] = (unsigned)numels[base + k];
+            if (numels[base + k] > nmax) nmax = numels[base + k];
+        }
+        size_t bx = (nmax + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
+        if (bx < 1) bx = 1;
+        if (bx > 256) bx = 256;
+        WUNET_LAUNCH(adam_kernel, dim3((unsigned)bx, cnt), dim3(WUNET_THREADS), 0, st, T, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), bc2_sqrt, (float)eps, step_size);
+        WUNET_CHECK_LAUNCH();
+    }
     return WUNET_OK;
 }
 

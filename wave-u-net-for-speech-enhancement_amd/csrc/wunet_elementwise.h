@@ -563,3 +563,38 @@ __global__ __launch_bounds__(WUNET_THREADS) void loss_bwd_kernel(int kind, const
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS)
         genh[i] = sc * loss_dterm(kind, enh[i] - clean[i]);
 }
+
+// ---------------------------------------------------------------------------- fused Adam
+// torch.optim.Adam(lr, betas, eps=1e-8, weight_decay=0, amsgrad=False) as the reference builds it
+// (train.py:31-35), for up to WUNET_ADAM_MAX tensors per launch: blockIdx.y = tensor, blockIdx.x strides inside it.
+// Same operation order as torch's single-tensor path: m.lerp_(g, 1-b1); v = v*b2 + (1-b2)*g*g;
+// denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom.
+#define WUNET_ADAM_MAX 64
+struct AdamTable {
+    float* p[WUNET_ADAM_MAX];
+    const float* g[WUNET_ADAM_MAX];
+    float* m[WUNET_ADAM_MAX];
+    float* v[WUNET_ADAM_MAX];
+    unsigned n[WUNET_ADAM_MAX];
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float one_minus_b1, float b2, float one_minus_b2,
+                                                              float bc2_sqrt, float eps, float step_size)
+{
+    const int t = blockIdx.y;
+    float* p = T.p[t];
+    const float* g = T.g[t];
+    float* m = T.m[t];
+    float* v = T.v[t];
+    const unsigned n = T.n[t];
+    for (unsigned i = blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += gridDim.x * WUNET_THREADS) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + one_minus_b1 * (gi - mi);
+        vi = vi * b2 + one_minus_b2 * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+    }
+}

@@ -130,6 +130,22 @@ class Engine:
         return g
 
 
+def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
+    """One fused Adam step over a list of tensors."""
+    for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
+        self._require(t, "adam tensor")
+    n = len(params)
+    numels = (ctypes.c_size_t * n)(*[p.numel() for p in params])
+    dev = params[0].device
+    with self._device_guard(dev):
+        self._check(self.lib.wunet_adam_step(n, self._ptrs(params), self._ptrs(grads), self._ptrs(exp_avg),
+                                             self._ptrs(exp_avg_sq), numels, float(lr), float(beta1), float(beta2),
+                                             float(eps), int(step), self._stream(dev)))
+
+
+Engine.adam_step = _adam_step
+
+
 class _NullCtx:
     def __enter__(self):
         return self
