@@ -258,3 +258,35 @@ def test_fused_adam_vs_torch(pkg, dev):
     for (k, a), (_, b) in zip(models[0].named_parameters(), models[1].named_parameters()):
         # both models see bit-identical gradients (deterministic kernels), so only the update arithmetic differs
         assert (a - b).abs().max().item() < 5e-7, k
+
+
+def test_grad_sync_rccl_single_rank(pkg, dev):
+    """The RCCL call path of parallel.GradSync (bucketed async all-reduce inside backward, side-stream join before
+    each collective) on one GPU: world_size 1, collectives forced on; gradients must equal the unsynchronised ones."""
+    import torch.distributed as dist
+    parallel = importlib.import_module(PKG_NAME + ".parallel")
+    import os
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29591")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        n, ci, B, T = 4, 8, 2, 256
+        noisy, clean = plan.golden_batch(B, T, 0)
+        grads = []
+        for sync in (None, parallel.GradSync(n_buckets=3, always_reduce=True)):
+            sd = plan.golden_state(n, ci, 0)
+            m = pkg.Model(n_layers=n, channels_interval=ci)
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+            m.to(dev).train()
+            m.grad_sync = sync
+            pkg.mse_loss()(_t(clean, dev), m(_t(noisy, dev))).backward()
+            torch.cuda.synchronize()
+            grads.append([p.grad.clone() for p in m.parameters()])
+        for a, b in zip(*grads):
+            assert torch.equal(a, b)
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -40,9 +40,10 @@ class GradSync:
     """Attach with `model.grad_sync = GradSync(...)`; the model's backward then runs the layer
     ranges through wunet_backward_range and enqueues one asynchronous all-reduce per finished bucket."""
 
-    def __init__(self, process_group=None, n_buckets=4):
+    def __init__(self, process_group=None, n_buckets=4, always_reduce=False):
         self.group = process_group
         self.n_buckets = n_buckets
+        self.always_reduce = always_reduce      # issue the collectives even at world_size 1 (single-GPU RCCL smoke test)
         self._ranges = {}
 
     def world_size(self):
@@ -61,7 +62,7 @@ class GradSync:
         for lb, le, fb, fe in self.ranges_for(params, nl):
             engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out, ws, grads,
                             layer_range=(lb, le))
-            if world > 1:
+            if world > 1 or (self.always_reduce and dist.is_initialized()):
                 seg = flat[fb:fe]
                 pending.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
         for work, seg in pending:
