@@ -1,0 +1,95 @@
+"""CPU tests (emulator engine) of the SURVEY.md §8(f) rows built so far: f2 train-step driver, f3 chunked inference,
+and the synthetic dataset plugin."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import emu_lib
+from conftest import PKG_NAME
+from oracle import c_oracle, plan
+
+
+@pytest.fixture(scope="module")
+def emu_engine():
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    return eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+
+
+def _model(n, ci, eng):
+    m = importlib.import_module(PKG_NAME + ".model").Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+    m._engine_override = eng
+    return m
+
+
+def test_chunked_inference_equals_reference_loop(emu_engine):
+    """f3: one batched forward over the chunks == the reference's sequential batch-1 loop (enhancement.py:57-69),
+    here run through the oracle chunk by chunk."""
+    inference = importlib.import_module(PKG_NAME + ".inference")
+    n, ci, sl = 2, 4, 64
+    m = _model(n, ci, emu_engine).eval()
+    T = 3 * sl + 17                                          # ragged: needs 47 samples of zero padding
+    rng = np.random.default_rng(5)
+    mix = rng.standard_normal((1, 1, T)).astype(np.float32)
+    out = inference.enhance(m, torch.from_numpy(mix), sample_length=sl, max_batch=3).numpy()
+    assert out.shape == (1, 1, T)
+    padded = np.concatenate([mix, np.zeros((1, 1, (-T) % sl), np.float32)], axis=-1)
+    ref = []
+    for k in range(padded.shape[-1] // sl):
+        sd = plan.golden_state(n, ci, 0)
+        ref.append(c_oracle.step(sd, padded[:, :, k * sl:(k + 1) * sl], None, n, ci, False, want_grads=False)["out"])
+    ref = np.concatenate(ref, axis=-1)[:, :, :T]
+    assert np.abs(out - ref).max() < 2e-5
+    with pytest.raises(ValueError):
+        inference.enhance(m, torch.zeros(2, 1, sl))         # batch 1 only, like the reference
+    with pytest.raises(RuntimeError):
+        inference.enhance(m.train(), torch.zeros(1, 1, sl))
+
+
+def test_trainer_plugin_runs_the_hot_loop(emu_engine, tmp_path):
+    """f2: Trainer(config, resume, model, loss, optimizer, loaders).train() == the hand-written reference loop."""
+    trainer_mod = importlib.import_module(PKG_NAME + ".trainer")
+    dataset_mod = importlib.import_module(PKG_NAME + ".dataset")
+    loss_mod = importlib.import_module(PKG_NAME + ".loss")
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    n, ci, sl = 2, 4, 64
+    ds = dataset_mod.Dataset(n_items=6, sample_length=sl, seed=1)
+    mixture, clean, name = ds[0]
+    assert mixture.shape == (1, sl) and clean.shape == (1, sl) and mixture.dtype == torch.float32 and isinstance(name, str)
+    loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False)
+
+    def make():
+        m = _model(n, ci, emu_engine)
+        crit = loss_mod.mse_loss()
+        crit._engine_override = emu_engine
+        opt = optim_mod.FusedAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        opt._engine_override = emu_engine
+        return m, crit, opt
+
+    cfg = {"root_dir": str(tmp_path), "experiment_name": "t", "trainer": {"epochs": 2, "save_checkpoint_interval": 2}}
+    m1, crit1, opt1 = make()
+    tr = trainer_mod.Trainer(cfg, False, m1, crit1, opt1, loader, None)
+    tr.device = torch.device("cpu")                          # the emulator engine takes host tensors
+    tr.model = m1.to("cpu")
+    tr.train()
+    m2, crit2, opt2 = make()
+    m2.train()
+    for _ in range(2):                                        # trainer/trainer.py:30-38 written out
+        for mix, cl, _ in loader:
+            opt2.zero_grad()
+            crit2(cl, m2(mix)).backward()
+            opt2.step()
+    for (k, a), (_, b) in zip(m1.named_parameters(), m2.named_parameters()):
+        assert torch.equal(a, b), k
+    assert len(tr.epoch_losses) == 2 and tr.epoch_losses[1] < tr.epoch_losses[0]
+    ck = torch.load((tmp_path / "t" / "checkpoints" / "latest_model.tar").as_posix())
+    assert set(ck) == {"epoch", "best_score", "optimizer", "model"} and ck["epoch"] == 2
+    assert set(ck["model"]) == set(plan.golden_state(n, ci, 0))          # the reference's 7*(2n+1)+2 keys
+    m3, crit3, opt3 = make()
+    tr3 = trainer_mod.Trainer(cfg, True, m3, crit3, opt3, loader, None)   # resume (base_trainer.py:62-81)
+    assert tr3.start_epoch == 3
+    for (k, a), (_, b) in zip(m1.named_parameters(), m3.named_parameters()):
+        assert torch.equal(a, b), k
