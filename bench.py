@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU (weak scaling)")
+    ap.add_argument("--mode", choices=["train", "forward"], default="train",
+                    help="train = the headline metric (BASELINE configs[2]/[3]); forward = eval-mode forward only "
+                         "(configs[1], the enhancement.py path) - an extra measurement, same JSON shape")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam (f1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -119,7 +122,13 @@ def main():
         model.grad_sync = parallel.GradSync(n_buckets=4)
     noisy, clean = synthetic_batch(args.batch, device, seed=rank)
 
+    if args.mode == "forward":
+        model.eval()
+
     def step():
+        if args.mode == "forward":
+            with torch.no_grad():
+                return model(noisy).sum()
         opt.zero_grad(set_to_none=True)
         out = model(noisy)
         loss = crit(clean, out)
@@ -201,7 +210,8 @@ def main():
     if rank == 0:
         per_gpu_fps = frames_per_s / world
         result = {
-            "metric": "16384-sample frames/sec fwd+bwd, 12-level Wave-U-Net",
+            "metric": "16384-sample frames/sec fwd+bwd, 12-level Wave-U-Net" if args.mode == "train"
+                      else "16384-sample frames/sec eval forward only, 12-level Wave-U-Net (extra, BASELINE configs[1])",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -210,9 +220,9 @@ def main():
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",
                        "global_batch": args.batch * world, "frame": FRAME,
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
-            "whole_step_tflops_per_gpu": per_gpu_fps * FWDBWD_FLOP_PER_FRAME / 1e12,
-            "whole_step_frac_of_fp32_peak": per_gpu_fps * FWDBWD_FLOP_PER_FRAME / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "whole_step_algorithmic_hbm_frac": per_gpu_fps * FWDBWD_BYTES_PER_FRAME / 1e9 / PEAK_HBM_GBS,
+            "whole_step_tflops_per_gpu": per_gpu_fps * (FWDBWD_FLOP_PER_FRAME if args.mode == "train" else FWD_FLOP_PER_FRAME) / 1e12,
+            "whole_step_frac_of_fp32_peak": per_gpu_fps * (FWDBWD_FLOP_PER_FRAME if args.mode == "train" else FWD_FLOP_PER_FRAME) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "whole_step_algorithmic_hbm_frac": per_gpu_fps * (FWDBWD_BYTES_PER_FRAME if args.mode == "train" else 33.18e6) / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -290,3 +290,24 @@ def test_grad_sync_rccl_single_rank(pkg, dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_chunked_inference_vs_reference_loop(pkg, dev):
+    """enhance() (one batched eval forward over all chunks) against the reference's sequential
+    batch-1 chunk loop (enhancement.py:57-69) run on the reference's ATen CPU path."""
+    inference = importlib.import_module(PKG_NAME + ".inference")
+    n, ci, sl = 12, 24, 16384
+    sd = plan.golden_state(n, ci, 0)
+    m = pkg.Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.to(dev).eval()
+    T = 5 * sl + 1234
+    g = torch.Generator().manual_seed(7)
+    mix = torch.rand(1, 1, T, generator=g) * 2 - 1
+    out = inference.enhance(m, mix.to(dev), sample_length=sl).cpu()
+    assert out.shape == (1, 1, T)
+    tsd = torch_port.state_to_torch(sd)
+    padded = torch.cat([mix, torch.zeros(1, 1, (-T) % sl)], dim=-1)
+    with torch.no_grad():
+        ref = torch.cat([torch_port.forward(tsd, c, n, ci, False) for c in torch.split(padded, sl, dim=-1)], dim=-1)[:, :, :T]
+    assert (out - ref).abs().max().item() < TOL
