@@ -1,0 +1,54 @@
+"""-m "not gpu": the C-ABI library builds, loads on a GPU-less box and exports every symbol that
+include/wunet_hip.h declares; the product path refuses to run without it and without a GPU."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import PKG_NAME, ROOT
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "wunet_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wunet_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_are_exported():
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    if not os.path.exists(lib_mod.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(lib_mod.LIB_PATH)          # HIP runtime initialises lazily: loading needs no GPU
+    names = _declared()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/wunet_hip.h but not exported"
+    assert sorted(lib_mod.EXPORTS) == names, "engine binding list and header disagree"
+
+
+def test_shape_errors_come_back_as_codes_not_crashes():
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    lib = lib_mod.declare(ctypes.CDLL(lib_mod.LIB_PATH))
+    h = ctypes.c_void_p()
+    assert lib.wunet_create(12, 24, 4, 16000, ctypes.byref(h)) == -1          # not a power of two (reference: 16000 fails too)
+    assert b"power of two" in lib.wunet_last_error()
+    assert lib.wunet_create(12, 24, 4, 8192, ctypes.byref(h)) == -1           # 8192 >> 12 = 2 < 4
+    assert lib.wunet_create(0, 24, 4, 16384, ctypes.byref(h)) == -1
+    assert lib.wunet_create(12, 24, 4, 16384, ctypes.byref(h)) == 0
+    assert lib.wunet_num_conv_layers(h) == 25
+    fwd, tot = lib.wunet_workspace_bytes(h, 0), lib.wunet_workspace_bytes(h, 1)
+    assert 0 < fwd < tot
+    lib.wunet_destroy(h)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU behaviour")
+def test_no_cpu_fallback(pkg):
+    m = pkg.Model(n_layers=2, channels_interval=4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        pkg.mse_loss()(torch.zeros(1, 1, 64), torch.zeros(1, 1, 64))
