@@ -31,7 +31,8 @@ def _build(n, ci, emu_engine):
     return m, sd, pkg_loss
 
 
-@pytest.mark.parametrize("n,ci,B,T,loss", [(2, 4, 2, 32, "mse"), (3, 8, 3, 64, "l1"), (2, 24, 1, 1024, "smooth_l1")])
+@pytest.mark.parametrize("n,ci,B,T,loss", [(2, 4, 2, 32, "mse"), (3, 8, 3, 64, "l1"), (2, 24, 1, 1024, "smooth_l1"),
+                                            (1, 5, 1, 8, "mse"), (3, 10, 3, 128, "smooth_l1")])
 def test_train_step_matches_oracle(emu_engine, n, ci, B, T, loss):
     m, sd, pkg_loss = _build(n, ci, emu_engine)
     noisy, clean = plan.golden_batch(B, T, 0)

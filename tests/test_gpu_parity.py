@@ -311,3 +311,22 @@ def test_chunked_inference_vs_reference_loop(pkg, dev):
     with torch.no_grad():
         ref = torch.cat([torch_port.forward(tsd, c, n, ci, False) for c in torch.split(padded, sl, dim=-1)], dim=-1)[:, :, :T]
     assert (out - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("n,ci,B,T,loss", [(1, 24, 1, 64, "mse"), (3, 10, 3, 512, "smooth_l1"), (5, 7, 5, 2048, "l1"),
+                                            (12, 24, 1, 16384, "mse"), (10, 24, 2, 65536, "mse")])
+def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
+    """Ragged / extreme shapes of the reference's domain: one level, batch 1 (BatchNorm over a single item),
+    channel intervals that are not multiples of 4/8/16/24, odd batches, 65536-sample frames."""
+    noisy, clean = plan.golden_batch(B, T, 11)
+    ref = c_oracle.step(plan.golden_state(n, ci, 0), noisy, clean, n, ci, True, loss, precision="f64")
+    m, out, lv = _run_model(pkg, dev, n, ci, noisy, clean, loss)
+    assert np.abs(out.detach().cpu().numpy() - ref["out"]).max() < TOL
+    assert abs(lv.item() - ref["loss"]) < 1e-5
+    for k, p in m.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            continue
+        r = ref["grads"][k]
+        err = np.abs(p.grad.cpu().numpy() - r).max()
+        rel = np.linalg.norm(p.grad.cpu().numpy().ravel() - r.ravel()) / (np.linalg.norm(r.ravel()) + 1e-12)
+        assert err < TOL and rel < 2e-2, (k, err, rel)
