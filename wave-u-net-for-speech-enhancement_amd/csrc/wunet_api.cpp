@@ -282,6 +282,23 @@ struct wunet_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
+namespace {
+int ensure_side_stream(wunet_ctx* c)
+{
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (c->side_dev != dev) {
+        if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); c->side = nullptr; }
+        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
+            return fail(WUNET_E_RUNTIME, "cannot create the side stream");
+        c->side_dev = dev;
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 const char* wunet_last_error(void) { return g_err.c_str(); }
@@ -401,6 +418,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     (void)save_for_backward;   // everything the backward needs (z, BN statistics, conv inputs) lives in the forward segment
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    // The skip half of each decoder input only depends on an encoder level and could run on the side stream during
+    // the encoder phase; measured on MI355X that is SLOWER (forward 4.24 vs 3.99 ms: the elementwise kernel steals
+    // L2/HBM bandwidth and CU slots from the encoder GEMMs), so it stays on the caller's stream.
+    hipStream_t sd = st;
     // 1. pack all forward weights into MFMA-fragment order (one launch)
     {
         PackTable tab{};
@@ -428,10 +449,18 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             if (l.kind == LK_DECIM) {
                 WUNET_LAUNCH(prep_decim_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa);
             } else {
+                // only the upsampled half here; the skip half was produced on the side stream during the encoder phase
                 const LayerPlan& k = c->ly[l.src1];
                 pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
                 pa.up_scale = l.L > 1 ? (float)(l.L / 2 - 1) / (float)(l.L - 1) : 0.f;
-                WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa);
+                const size_t nu4 = (size_t)c->B * l.c0 * l.L / 4;
+                size_t ub = (nu4 + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (ub > 8192) ub = 8192;
+                WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)ub), dim3(WUNET_THREADS), 0, st, pa, 0, l.c0);
+                if (i == c->n + 1 && sd != st) {          // first decoder: join the skip halves
+                    hipEventRecord(c->ev_join, sd);
+                    hipStreamWaitEvent(st, c->ev_join, 0);
+                }
             }
             WUNET_CHECK_LAUNCH();
             xin = ws + l.xin;
@@ -468,6 +497,24 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
         WUNET_CHECK_LAUNCH();
+        if (i < c->n) {
+            // skip half of decoder (2n-i)'s input = LeakyReLU(BN(z_i)): off the critical path
+            const LayerPlan& d = c->ly[2 * c->n - i];
+            const LayerPlan& p = c->ly[d.src0];
+            PrepArgs pa{};
+            pa.z0 = ws + p.z; pa.a0 = ws + p.a; pa.s0 = ws + p.s;      // unused by the skip half (not yet computed)
+            pa.z1 = ws + l.z; pa.a1 = ws + l.a; pa.s1 = ws + l.s; pa.x = ws + d.xin;
+            pa.B = c->B; pa.C0 = d.c0; pa.C1 = d.cin - d.c0; pa.L = d.L; pa.logL = d.logL;
+            const size_t ns4 = (size_t)c->B * pa.C1 * d.L / 4;
+            size_t kb = (ns4 + WUNET_THREADS - 1) / WUNET_THREADS;
+            if (kb > 8192) kb = 8192;
+            if (sd != st) {
+                hipEventRecord(c->ev_fork, st);
+                hipStreamWaitEvent(sd, c->ev_fork, 0);
+            }
+            WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)kb), dim3(WUNET_THREADS), 0, sd, pa, d.c0, d.cin);
+            WUNET_CHECK_LAUNCH();
+        }
     }
     // 3. head
     {
@@ -495,18 +542,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
     const int NL = c->NL, n = c->n;
     // weight gradients run on a side stream: they only depend on g_z and x of their own layer, so the HBM-bound
     // gradient-assembly kernels of the next layers overlap with them instead of idling the matrix cores
-    {
-        int dev = 0;
-        hipGetDevice(&dev);
-        if (c->side_dev != dev) {
-            if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); c->side = nullptr; }
-            if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
-                return fail(WUNET_E_RUNTIME, "cannot create the side stream");
-            c->side_dev = dev;
-        }
-    }
+    if (ensure_side_stream(c)) return WUNET_E_RUNTIME;
     hipStream_t sd = g_prof_on ? st : c->side;      // the per-kernel profiler serialises everything on one stream
 
     if (layer_end == NL) {

@@ -67,7 +67,7 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red)
 // momentum 0.1) and num_batches_tracked += 1 (nn.BatchNorm1d defaults, reference unet_basic.py:12,25,55).
 // Eval: scale/shift from the running statistics.
 struct BnFwdArgs {
-    const float* stats;   // [rows][C][2] or nullptr (eval)
+    const float* stats;   // [C][rows][2] or nullptr (eval)
     int rows;
     const float* bias;    // conv bias [C]
     const float* gamma;
@@ -120,10 +120,11 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArg
         return;
     }
     double s1 = 0.0, s2 = 0.0;
+    const float2* st = reinterpret_cast<const float2*>(A.stats) + (size_t)c * A.rows;     // [C][rows][2]
     for (int r = tid; r < A.rows; r += WUNET_THREADS) {
-        const float* st = A.stats + ((size_t)r * A.C + c) * 2;
-        s1 += (double)st[0];
-        s2 += (double)st[1];
+        const float2 v = st[r];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
     }
     block_sum2(s1, s2, red);
     if (tid == 0) bn_finalize_core(A, c, s1, s2);
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
     block_sum2(s1, s2, red);
     if (tid == 0) {
         if (gridDim.y > 1) {
-            float* st = stats_rows + ((size_t)blockIdx.y * A.C + c) * 2;
+            float* st = stats_rows + ((size_t)c * gridDim.y + blockIdx.y) * 2;
             st[0] = (float)s1;
             st[1] = (float)s2;
         } else if (A.training) bn_finalize_core(A, c, s1, s2);
@@ -467,14 +468,16 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
     }
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A)
+// channels [cbeg, cend) of the decoder input: the skip half only depends on an encoder level, so the host
+// runs it on a side stream during the encoder phase and only the upsampled half sits on the critical path
+__global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, int cbeg, int cend)
 {
-    const int l4n = A.L >> 2, C = A.C0 + A.C1, Lh = A.L >> 1;
-    const size_t total = (size_t)A.B * C * l4n;
+    const int l4n = A.L >> 2, C = A.C0 + A.C1, Lh = A.L >> 1, nc = cend - cbeg;
+    const size_t total = (size_t)A.B * nc * l4n;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
         const size_t row = i >> (A.logL - 2);
         const int l4 = (int)(i & (size_t)(l4n - 1));
-        const int b = (int)(row / (size_t)C), c = (int)(row - (size_t)b * C);
+        const int b = (int)(row / (size_t)nc), c = cbeg + (int)(row - (size_t)b * nc);
         float4 o;
         if (c < A.C0) {
             const float a = A.a0[c], s = A.s0[c];
@@ -494,7 +497,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A)
             o.x = wunet_lrelu(a * v.x + s); o.y = wunet_lrelu(a * v.y + s);
             o.z = wunet_lrelu(a * v.z + s); o.w = wunet_lrelu(a * v.w + s);
         }
-        reinterpret_cast<float4*>(A.x)[i] = o;
+        reinterpret_cast<float4*>(A.x + ((size_t)b * C + c) * A.L)[l4] = o;
     }
 }
 

@@ -30,7 +30,7 @@ struct ConvArgs {
     const float* wpk;   // packed weights [Mtiles_padded][CinP][TAPS][16]
     const float* bias;  // [Cout] or nullptr
     float* out;         // [B][Cout][L]  (+ z-slice * split_stride when split-K)
-    float* stats;       // nullptr or [gridDim.x*4][Cout][2]  (sum, sum of squares of the bias-free conv)
+    float* stats;       // nullptr or [Cout][gridDim.x*4][2]  (sum, sum of squares of the bias-free conv)
     int B, Cin, Cout, CinP, L, logL;
     int seg, seg_shift, segw;      // segw = seg + 16
     int rowp;                      // LDS row stride
@@ -167,7 +167,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
                 }
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
                 if (i16 == 0 && co < A.Cout) {
-                    float* st = A.stats + ((size_t)(blockIdx.x * WUNET_WAVES + wave) * A.Cout + co) * 2;
+                    // [channel][row][2]: the finalize kernel then reads each channel's rows contiguously
+                    float* st = A.stats + ((size_t)co * (gridDim.x * WUNET_WAVES) + (blockIdx.x * WUNET_WAVES + wave)) * 2;
                     st[0] = s1[r];
                     st[1] = s2[r];
                 }
