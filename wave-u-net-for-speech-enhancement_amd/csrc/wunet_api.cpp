@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -543,7 +544,8 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
     // weight gradients run on a side stream: they only depend on g_z and x of their own layer, so the HBM-bound
     // gradient-assembly kernels of the next layers overlap with them instead of idling the matrix cores
     if (ensure_side_stream(c)) return WUNET_E_RUNTIME;
-    hipStream_t sd = g_prof_on ? st : c->side;      // the per-kernel profiler serialises everything on one stream
+    static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr;     // A/B switch for measurements
+    hipStream_t sd = (g_prof_on || no_side) ? st : c->side;      // the per-kernel profiler serialises everything on one stream
 
     if (layer_end == NL) {
         // flipped/transposed weights for every data gradient (one launch)
