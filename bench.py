@@ -34,10 +34,25 @@ PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_
 PEAK_HBM_GBS = 8000.0
 
 
-def synthetic_batch(batch, device, seed):
+def net_flops_bytes(n, ci, frame):
+    """Algorithmic forward flops and bytes per frame: sum over the 2n+2 convs of 2*Cin*Cout*k*L and
+    4*(Cin+Cout)*L."""
+    plan = importlib.import_module(PKG + ".plan")
+    fl = by = 0.0
+    shapes = plan.conv_layer_shapes(n, ci)
+    for i, (c_in, c_out, k) in enumerate(shapes):
+        L = frame >> (i if i <= n else 2 * n - i)
+        fl += 2.0 * c_in * c_out * k * L
+        by += 4.0 * (c_in + c_out) * L
+    fl += 2.0 * (ci + 1) * frame
+    by += 4.0 * (ci + 2) * frame
+    return fl, by
+
+
+def synthetic_batch(batch, device, seed, frame=FRAME):
     g = torch.Generator().manual_seed(seed)
-    clean = torch.rand(batch, 1, FRAME, generator=g) * 2 - 1
-    noisy = clean + 0.1 * torch.randn(batch, 1, FRAME, generator=g)
+    clean = torch.rand(batch, 1, frame, generator=g) * 2 - 1
+    noisy = clean + 0.1 * torch.randn(batch, 1, frame, generator=g)
     return noisy.to(device), clean.to(device)
 
 
@@ -88,6 +103,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU (weak scaling)")
+    ap.add_argument("--layers", type=int, default=N_LAYERS, help="extra measurements only: net depth (default 12)")
+    ap.add_argument("--frame", type=int, default=FRAME, help="extra measurements only: samples per frame (default 16384)")
     ap.add_argument("--mode", choices=["train", "forward"], default="train",
                     help="train = the headline metric (BASELINE configs[2]/[3]); forward = eval-mode forward only "
                          "(configs[1], the enhancement.py path) - an extra measurement, same JSON shape")
@@ -113,14 +130,18 @@ def main():
     engine_mod = importlib.import_module(PKG + ".engine")
 
     torch.manual_seed(0)                         # same init on every rank (reference train.py:12)
-    model = pkg.Model(n_layers=N_LAYERS, channels_interval=CI).to(device).train()
+    model = pkg.Model(n_layers=args.layers, channels_interval=CI).to(device).train()
     crit = pkg.smooth_l1_loss()
     optim_mod = importlib.import_module(PKG + ".optim")
     adam_cls = torch.optim.Adam if args.torch_adam else optim_mod.FusedAdam     # reference train.py:31-35
     opt = adam_cls(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     if world > 1:
         model.grad_sync = parallel.GradSync(n_buckets=4)
-    noisy, clean = synthetic_batch(args.batch, device, seed=rank)
+    noisy, clean = synthetic_batch(args.batch, device, seed=rank, frame=args.frame)
+    default_net = args.layers == N_LAYERS and args.frame == FRAME
+    fwd_flop, fwd_bytes = net_flops_bytes(args.layers, CI, args.frame)
+    step_flop = 3.0 * fwd_flop - 2.0 * (1 * CI * 15 * args.frame) if args.mode == "train" else fwd_flop   # no dgrad for encoder[0]
+    step_bytes = 3.0 * fwd_bytes if args.mode == "train" else fwd_bytes
 
     if args.mode == "forward":
         model.eval()
@@ -210,19 +231,20 @@ def main():
     if rank == 0:
         per_gpu_fps = frames_per_s / world
         result = {
-            "metric": "16384-sample frames/sec fwd+bwd, 12-level Wave-U-Net" if args.mode == "train"
-                      else "16384-sample frames/sec eval forward only, 12-level Wave-U-Net (extra, BASELINE configs[1])",
+            "metric": ("16384-sample frames/sec fwd+bwd, 12-level Wave-U-Net" if args.mode == "train"
+                       else "16384-sample frames/sec eval forward only, 12-level Wave-U-Net (extra, BASELINE configs[1])")
+                      if default_net else f"{args.frame}-sample frames/sec, {args.layers}-level Wave-U-Net, mode={args.mode} (extra)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"unet_basic 12-level, {FRAME}-sample frames, batch={args.batch} per GPU, fp32, "
+            "config": {"workload": f"unet_basic {args.layers}-level, {args.frame}-sample frames, batch={args.batch} per GPU, fp32, "
                                    "training-mode forward + smooth_l1 + backward + " + ("torch.optim.Adam" if args.torch_adam else "fused HIP Adam") + " step "
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",
-                       "global_batch": args.batch * world, "frame": FRAME,
+                       "global_batch": args.batch * world, "frame": args.frame,
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
-            "whole_step_tflops_per_gpu": per_gpu_fps * (FWDBWD_FLOP_PER_FRAME if args.mode == "train" else FWD_FLOP_PER_FRAME) / 1e12,
-            "whole_step_frac_of_fp32_peak": per_gpu_fps * (FWDBWD_FLOP_PER_FRAME if args.mode == "train" else FWD_FLOP_PER_FRAME) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "whole_step_algorithmic_hbm_frac": per_gpu_fps * (FWDBWD_BYTES_PER_FRAME if args.mode == "train" else 33.18e6) / 1e9 / PEAK_HBM_GBS,
+            "whole_step_tflops_per_gpu": per_gpu_fps * step_flop / 1e12,
+            "whole_step_frac_of_fp32_peak": per_gpu_fps * step_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "whole_step_algorithmic_hbm_frac": per_gpu_fps * step_bytes / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -39,7 +39,8 @@ typedef struct wunet_ctx wunet_ctx;
 const char* wunet_last_error(void);
 
 /* Replaces Model.__init__ shape bookkeeping (model/unet_basic.py:33-75) for one (batch, length).
- * length must be a power of two with length >> n_layers >= 4.  Host-side object, no device memory. */
+ * length must be a power of two >= 4 with length >> n_layers >= 1 (levels of 1-2 samples take a scalar path).
+ * Host-side object, no device memory. */
 int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out);
 void wunet_destroy(wunet_ctx* ctx);
 

@@ -36,7 +36,7 @@ def test_shape_errors_come_back_as_codes_not_crashes():
     h = ctypes.c_void_p()
     assert lib.wunet_create(12, 24, 4, 16000, ctypes.byref(h)) == -1          # not a power of two (reference: 16000 fails too)
     assert b"power of two" in lib.wunet_last_error()
-    assert lib.wunet_create(12, 24, 4, 8192, ctypes.byref(h)) == -1           # 8192 >> 12 = 2 < 4
+    assert lib.wunet_create(12, 24, 4, 2048, ctypes.byref(h)) == -1           # 2048 >> 12 = 0: deeper than log2(T)
     assert lib.wunet_create(0, 24, 4, 16384, ctypes.byref(h)) == -1
     assert lib.wunet_create(12, 24, 4, 16384, ctypes.byref(h)) == 0
     assert lib.wunet_num_conv_layers(h) == 25

@@ -32,7 +32,8 @@ def _build(n, ci, emu_engine):
 
 
 @pytest.mark.parametrize("n,ci,B,T,loss", [(2, 4, 2, 32, "mse"), (3, 8, 3, 64, "l1"), (2, 24, 1, 1024, "smooth_l1"),
-                                            (1, 5, 1, 8, "mse"), (3, 10, 3, 128, "smooth_l1")])
+                                            (1, 5, 1, 8, "mse"), (3, 10, 3, 128, "smooth_l1"),
+                                            (4, 4, 2, 16, "mse"), (5, 6, 3, 64, "l1"), (3, 8, 2, 16, "smooth_l1")])   # middle of 1 / 2 samples
 def test_train_step_matches_oracle(emu_engine, n, ci, B, T, loss):
     m, sd, pkg_loss = _build(n, ci, emu_engine)
     noisy, clean = plan.golden_batch(B, T, 0)

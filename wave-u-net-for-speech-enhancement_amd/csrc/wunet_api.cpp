@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "wunet_elementwise.h"
+#include "wunet_tiny.h"
 #include "wunet_kernels.h"
 #include "wunet_launch.h"
 #include "wunet_hip.h"
@@ -309,8 +310,8 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
     if (!out) return fail(WUNET_E_ARG, "out is null");
     if (n_layers < 1 || 2 * n_layers + 1 > WUNET_MAX_CONV_LAYERS) return fail(WUNET_E_ARG, "n_layers=%d unsupported (1..16)", n_layers);
     if (channels_interval < 1 || batch < 1) return fail(WUNET_E_ARG, "bad channels_interval/batch");
-    if (!is_pow2(length) || (length >> n_layers) < 4)
-        return fail(WUNET_E_ARG, "length=%d unsupported: must be a power of two with length >> n_layers >= 4", length);
+    if (!is_pow2(length) || (length >> n_layers) < 1 || length < 4)
+        return fail(WUNET_E_ARG, "length=%d unsupported: must be a power of two >= 4 with length >> n_layers >= 1", length);
     const int n = n_layers, ci = channels_interval, B = batch, T = length;
     if ((long long)B * (2 * n + 1) * ci * T >= (1LL << 32)) return fail(WUNET_E_ARG, "tensor too large for 32-bit offsets");
 
@@ -339,12 +340,14 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         l.f = plan_conv(B, l.L, l.cout, l.cin, l.taps);
         l.d = plan_conv(B, l.L, l.cin, l.cout, l.taps);
         l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
+        if (l.L < 4) { l.f.ksplit = 1; l.d.ksplit = 1; }    // levels of 1-2 samples run the scalar kernels of wunet_tiny.h
         l.f_rows = l.f.grid_x * WUNET_WAVES;
         l.f_wpk = wpk;
         wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
         if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
         if (l.f.ksplit > 1 && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
         if (l.f.ksplit > 1 && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
+        if (l.L < 4 && (size_t)B * l.cout * l.L > spart_max) spart_max = (size_t)B * l.cout * l.L;
         if (i > 0 && l.d.ksplit > 1 && (size_t)l.d.ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d.ksplit * B * l.cin * l.L;
         l.z = off; off += align64((size_t)B * l.cout * l.L);
         l.a = off; off += align64(l.cout);
@@ -447,32 +450,40 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             const size_t n4 = (size_t)c->B * l.cin * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
-            if (l.kind == LK_DECIM) {
+            if (l.L < 4) {
+                if (l.kind == LK_UPCAT) {
+                    const LayerPlan& k = c->ly[l.src1];
+                    pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
+                    pa.up_scale = l.L > 1 ? (float)(l.L / 2 - 1) / (float)(l.L - 1) : 0.f;
+                }
+                const size_t ne = (size_t)c->B * l.cin * l.L;
+                WUNET_LAUNCH(prep_scalar_kernel, dim3((unsigned)((ne + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st, pa,
+                             l.kind == LK_UPCAT ? 1 : 0);
+            } else if (l.kind == LK_DECIM) {
                 WUNET_LAUNCH(prep_decim_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa);
             } else {
-                // only the upsampled half here; the skip half was produced on the side stream during the encoder phase
                 const LayerPlan& k = c->ly[l.src1];
                 pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
                 pa.up_scale = l.L > 1 ? (float)(l.L / 2 - 1) / (float)(l.L - 1) : 0.f;
-                const size_t nu4 = (size_t)c->B * l.c0 * l.L / 4;
-                size_t ub = (nu4 + WUNET_THREADS - 1) / WUNET_THREADS;
-                if (ub > 8192) ub = 8192;
-                WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)ub), dim3(WUNET_THREADS), 0, st, pa, 0, l.c0);
-                if (i == c->n + 1 && sd != st) {          // first decoder: join the skip halves
-                    hipEventRecord(c->ev_join, sd);
-                    hipStreamWaitEvent(st, c->ev_join, 0);
-                }
+                WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa, 0, l.cin);
             }
             WUNET_CHECK_LAUNCH();
             xin = ws + l.xin;
         }
         // 2b. conv (+ bias, + per-wave BN statistics partials) on the matrix cores
-        const bool split = l.f.ksplit > 1;
-        const ConvArgs a = make_conv_args(xin, l.cin, ws + c->wpkf_off + l.f_wpk, split ? nullptr : params[4 * i + 1],
-                                          split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr,
-                                          c->B, l.cout, l.L, l.taps, l.f, (size_t)c->B * l.cout * l.L);
-        int rc = launch_conv(l.taps, "fwd", a, l.f, st);
-        if (rc) return rc;
+        const bool tiny = l.L < 4;
+        const bool split = l.f.ksplit > 1 || tiny;      // both leave a bias-free result in the split buffer
+        if (tiny) {
+            const size_t no = (size_t)c->B * l.cout * l.L;
+            WUNET_LAUNCH(tiny_conv_kernel, dim3((unsigned)((no + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st,
+                         xin, params[4 * i], ws + c->spart_off, c->B, l.cin, l.cout, l.L, l.logL, l.taps, 0);
+        } else {
+            const ConvArgs a = make_conv_args(xin, l.cin, ws + c->wpkf_off + l.f_wpk, split ? nullptr : params[4 * i + 1],
+                                              split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr,
+                                              c->B, l.cout, l.L, l.taps, l.f, (size_t)c->B * l.cout * l.L);
+            int rc = launch_conv(l.taps, "fwd", a, l.f, st);
+            if (rc) return rc;
+        }
         WUNET_CHECK_LAUNCH();
         // 2c. BatchNorm statistics -> scale/shift for the consumers (+ running stats)
         BnFwdArgs b{};
@@ -489,7 +500,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             if (rs > 64) rs = 64;
             b.rows = rs;
             WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout, rs), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
-                         l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off);
+                         tiny ? 1 : l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off);
             if (rs > 1) {
                 WUNET_CHECK_LAUNCH();
                 WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
@@ -498,24 +509,6 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
         WUNET_CHECK_LAUNCH();
-        if (i < c->n) {
-            // skip half of decoder (2n-i)'s input = LeakyReLU(BN(z_i)): off the critical path
-            const LayerPlan& d = c->ly[2 * c->n - i];
-            const LayerPlan& p = c->ly[d.src0];
-            PrepArgs pa{};
-            pa.z0 = ws + p.z; pa.a0 = ws + p.a; pa.s0 = ws + p.s;      // unused by the skip half (not yet computed)
-            pa.z1 = ws + l.z; pa.a1 = ws + l.a; pa.s1 = ws + l.s; pa.x = ws + d.xin;
-            pa.B = c->B; pa.C0 = d.c0; pa.C1 = d.cin - d.c0; pa.L = d.L; pa.logL = d.logL;
-            const size_t ns4 = (size_t)c->B * pa.C1 * d.L / 4;
-            size_t kb = (ns4 + WUNET_THREADS - 1) / WUNET_THREADS;
-            if (kb > 8192) kb = 8192;
-            if (sd != st) {
-                hipEventRecord(c->ev_fork, st);
-                hipStreamWaitEvent(sd, c->ev_fork, 0);
-            }
-            WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)kb), dim3(WUNET_THREADS), 0, sd, pa, d.c0, d.cin);
-            WUNET_CHECK_LAUNCH();
-        }
     }
     // 3. head
     {
@@ -581,19 +574,23 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         p.z = ws + l.z; p.a = ws + l.a; p.s = ws + l.s; p.mean = ws + l.mean; p.rstd = ws + l.rstd;
         p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL;
         const dim3 ga(l.cout, l.a_split);
+        const bool tiny = l.L < 4;
         if (i == NL - 1) {
             p.g0 = ws + c->gh_off; p.g1 = params[4 * NL];
-            WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);
+            if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);
         } else if (i >= n) {
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + nx.dx; p.Cg0 = nx.cin;
             p.up_scale = (float)(l.L - 1) / (float)(2 * l.L - 1);
-            WUNET_LAUNCH(pass_a_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
+            if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else WUNET_LAUNCH(pass_a_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
         } else {
             const LayerPlan& dc = c->ly[2 * n - i];
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + dc.dx; p.Cg0 = dc.cin; p.coff = dc.c0; p.g1 = ws + nx.dx;
-            WUNET_LAUNCH(pass_a_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
+            if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else WUNET_LAUNCH(pass_a_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
         }
         WUNET_CHECK_LAUNCH();
         BnBwdArgs b{};
@@ -608,6 +605,11 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
+            if (tiny)
+                WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
+                             (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
+                             (size_t)c->B * l.cout * l.L, ws + l.g);
+            else
             WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                          (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
             WUNET_CHECK_LAUNCH();
@@ -620,19 +622,30 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 hipStreamWaitEvent(sd, c->ev_fork, 0);
             }
             const float* xin = i == 0 ? noisy : ws + l.xin;
-            const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
-            int rc = launch_wgrad_any(l.taps, w, l.w, sd);
-            if (rc) return rc;
-            WUNET_CHECK_LAUNCH();
             const size_t nw = (size_t)l.cout * l.cin * l.taps;
-            size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
-            if (blocks > 2048) blocks = 2048;
-            WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
-                         (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
-            WUNET_CHECK_LAUNCH();
+            if (tiny) {
+                WUNET_LAUNCH(tiny_wgrad_kernel, dim3((unsigned)((nw + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, sd,
+                             (const float*)(ws + l.g), xin, grads[4 * i], c->B, l.cin, l.cout, l.L, l.taps);
+                WUNET_CHECK_LAUNCH();
+            } else {
+                const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
+                int rc = launch_wgrad_any(l.taps, w, l.w, sd);
+                if (rc) return rc;
+                WUNET_CHECK_LAUNCH();
+                size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (blocks > 2048) blocks = 2048;
+                WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
+                             (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
+                WUNET_CHECK_LAUNCH();
+            }
         }
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
-        if (i > 0) {
+        if (i > 0 && tiny) {
+            const size_t nd = (size_t)c->B * l.cin * l.L;
+            WUNET_LAUNCH(tiny_conv_kernel, dim3((unsigned)((nd + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st,
+                         (const float*)(ws + l.g), params[4 * i], ws + l.dx, c->B, l.cout, l.cin, l.L, l.logL, l.taps, 1);
+            WUNET_CHECK_LAUNCH();
+        } else if (i > 0) {
             const bool split = l.d.ksplit > 1;
             const size_t nd = (size_t)c->B * l.cin * l.L;
             const ConvArgs a = make_conv_args(ws + l.g, l.cout, ws + c->wpkb_off + l.d_wpk, nullptr,
