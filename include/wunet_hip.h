@@ -44,6 +44,12 @@ const char* wunet_last_error(void);
 int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out);
 void wunet_destroy(wunet_ctx* ctx);
 
+/* Optional: run the forward convs and data gradients of the large levels (>= 256 samples) as fp16-split GEMMs
+ * (x = hi + lo in fp16, three v_mfma_f32_16x16x32_f16 passes, fp32 accumulation; gradients pre-scaled by a power of
+ * two).  Accuracy is at the fp32 noise floor; arithmetic is no longer bit-identical to the fp32 path.
+ * Changes the workspace size: call before wunet_workspace_bytes.  No reference counterpart. */
+int wunet_set_h3(wunet_ctx* ctx, int enable);
+
 /* Bytes of device workspace the caller must provide to wunet_forward (with_backward=0: inference;
  * with_backward=1: also holds everything wunet_backward needs). */
 size_t wunet_workspace_bytes(const wunet_ctx* ctx, int with_backward);

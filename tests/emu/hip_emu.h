@@ -33,6 +33,8 @@ struct BlockState {
     float* dyn_smem;
     float wave_a[4][2][64];
     float wave_b[4][2][64];
+    unsigned short wave_a8[4][2][64][8];
+    unsigned short wave_b8[4][2][64][8];
 };
 FiberState& cur_fiber();
 BlockState& cur_block();
@@ -59,6 +61,49 @@ inline wunet_f4 wunet_ld4(const float* p) { wunet_f4 r; std::memcpy(r.v, p, 16);
 inline void wunet_st4(float* p, wunet_f4 v) { std::memcpy(p, v.v, 16); }
 inline wunet_f4 wunet_sel4(bool ok, wunet_f4 v) { return ok ? v : wunet_f4{{0.f, 0.f, 0.f, 0.f}}; }
 
+// ---- fp16 emulation (round to nearest even, subnormals kept), storage as raw 16-bit words
+typedef unsigned short wunet_half;
+inline wunet_half wunet_f2h(float f)
+{
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (wunet_half)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));   // inf / nan
+    if (x >= 0x477ff000u) return (wunet_half)(sign | 0x7c00u);                                        // overflow -> inf
+    if (x < 0x33000001u) return (wunet_half)sign;                                                     // underflow -> 0
+    int e = (int)(x >> 23) - 127;
+    uint32_t m = (x & 0x7fffffu) | 0x800000u;
+    int shift = e < -14 ? (13 + (-14 - e)) : 13;           // bits to drop
+    uint32_t half_m = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (half_m & 1))) half_m++;
+    uint32_t h = e < -14 ? half_m : (((uint32_t)(e + 15) << 10) + (half_m - 0x400u));
+    return (wunet_half)(sign | h);
+}
+inline float wunet_h2f(wunet_half h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1f, m = h & 0x3ffu, x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int sh = 0; while (!(m & 0x400u)) { m <<= 1; ++sh; } x = sign | ((uint32_t)(113 - sh) << 23) | ((m & 0x3ffu) << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; std::memcpy(&f, &x, 4); return f;
+}
+struct wunet_h8 { wunet_half v[8]; wunet_half& operator[](int i) { return v[i]; } const wunet_half& operator[](int i) const { return v[i]; } };
+inline wunet_h8 wunet_ldh8(const wunet_half* p) { wunet_h8 r; std::memcpy(r.v, p, 16); return r; }
+inline void wunet_sth8(wunet_half* p, wunet_h8 v) { std::memcpy(p, v.v, 16); }
+inline void wunet_put_half(wunet_h8& v, int e, wunet_half h) { v.v[e] = h; }
+inline unsigned wunet_fbits(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
+inline unsigned atomicMax(unsigned* p, unsigned v)
+{
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+inline wunet_h8 wunet_selh8(bool ok, wunet_h8 v) { return ok ? v : wunet_h8{{0, 0, 0, 0, 0, 0, 0, 0}}; }
+
 inline wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
 {
     emu::FiberState& f = emu::cur_fiber();
@@ -73,6 +118,28 @@ inline wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
         const int row = (lane >> 4) * 4 + r;
         float d = c[r];
         for (int k = 0; k < 4; ++k) d = fmaf(blk.wave_a[wave][par][k * 16 + row], blk.wave_b[wave][par][k * 16 + col], d);
+        c[r] = d;
+    }
+    return c;
+}
+
+// v_mfma_f32_16x16x32_f16 emulation: products of halfs are exact in fp32, accumulated in k order
+inline wunet_f4 wunet_mfma16h(wunet_h8 a, wunet_h8 b, wunet_f4 c)
+{
+    emu::FiberState& f = emu::cur_fiber();
+    emu::BlockState& blk = emu::cur_block();
+    const int lane = f.tidx.x & 63, wave = f.tidx.x >> 6, par = f.op_parity;
+    f.op_parity ^= 1;
+    std::memcpy(&blk.wave_a8[wave][par][lane][0], a.v, 16);
+    std::memcpy(&blk.wave_b8[wave][par][lane][0], b.v, 16);
+    emu::wave_barrier();
+    const int col = lane & 15;
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) * 4 + r;
+        float d = c[r];
+        for (int q = 0; q < 4; ++q)
+            for (int e = 0; e < 8; ++e)
+                d += wunet_h2f(blk.wave_a8[wave][par][q * 16 + row][e]) * wunet_h2f(blk.wave_b8[wave][par][q * 16 + col][e]);
         c[r] = d;
     }
     return c;

@@ -336,3 +336,35 @@ def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
         # gradients (f32-vs-f64 oracle, measured), so the absolute bar is 3e-4 there; the relative bar stays.
         tol_g = TOL if B * (T >> n) >= 8 else 3e-4
         assert err < max(tol_g, 2e-3 * np.abs(r).max()) and rel < 2e-2, (k, err, rel)
+
+
+def test_fp16_split_path_matches_reference(pkg, dev):
+    """The opt-in fp16-split ("h3") GEMMs of the large levels (3 passes of v_mfma_f32_16x16x32_f16 on hi/lo halves,
+    power-of-two scaled gradients): same 1e-4 bar against the reference's ATen CPU path as the fp32 kernels, at a batch
+    large enough (16 x 16384) for the planner to route the big layers through them."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    n, ci, B, T = 12, 24, 16, 16384
+    noisy, clean = plan.golden_batch(B, T, 5)
+    sd = plan.golden_state(n, ci, 0)
+    m = pkg.Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.to(dev).train()
+    m._engine_override = eng_mod.Engine(h3=True)
+    crit = pkg.smooth_l1_loss()
+    out = m(_t(noisy, dev))
+    lv = crit(_t(clean, dev), out)
+    lv.backward()
+    torch.cuda.synchronize()
+    tsd = torch_port.state_to_torch(plan.golden_state(n, ci, 0), requires_grad=True)
+    o2 = torch_port.forward(tsd, torch.from_numpy(noisy), n, ci, True)
+    l2 = torch_port.loss_value("smooth_l1", torch.from_numpy(clean), o2)
+    l2.backward()
+    assert (out.detach().cpu() - o2.detach()).abs().max().item() < TOL
+    assert abs(lv.item() - l2.item()) < 1e-5
+    for k, p in m.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            continue
+        ref = tsd[k].grad
+        err = (p.grad.cpu() - ref).abs().max().item()
+        rel = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        assert err < TOL and rel < 2e-2, (k, err, rel)

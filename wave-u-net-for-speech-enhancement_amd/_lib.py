@@ -14,7 +14,7 @@ EXPORTS = [
     "wunet_backward", "wunet_backward_range", "wunet_loss_scratch_bytes", "wunet_loss_forward",
     "wunet_loss_backward", "wunet_layer_info", "wunet_num_conv_layers", "wunet_op_conv1d",
     "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
-    "wunet_adam_step",
+    "wunet_adam_step", "wunet_set_h3",
 ]
 
 _vp = ctypes.c_void_p
@@ -46,6 +46,7 @@ def declare(lib):
     lib.wunet_op_conv1d_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_adam_step.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_longlong, _vp]
+    lib.wunet_set_h3.argtypes = [_vp, _i]
     lib.wunet_profile_enable.argtypes = [_i]
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
     lib.wunet_profile_collect.restype = ctypes.c_longlong

@@ -11,6 +11,7 @@
 
 #include "wunet_elementwise.h"
 #include "wunet_tiny.h"
+#include "wunet_h3_elem.h"
 #include "wunet_kernels.h"
 #include "wunet_launch.h"
 #include "wunet_hip.h"
@@ -268,6 +269,11 @@ struct LayerPlan {
     size_t f_wpk, d_wpk; // float offsets inside the forward / backward weight packs
     // workspace (float offsets)
     size_t z, a, s, mean, rstd, xin, g, dx, k1, k2, k3;
+    // fp16-split path (large levels only)
+    int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
+    int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
+    size_t xh, xl;                // split activated input (float offsets)
+    size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
 };
 
 }  // namespace
@@ -278,6 +284,9 @@ struct wunet_ctx {
     size_t stats_off, wpkf_off, spart_off, fwd_floats;
     size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
     int head_blocks;
+    int h3 = 0;                   // fp16-split GEMMs enabled for the large levels
+    size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_gz_hi, h3_gz_lo, h3_slot;   // float offsets
+    size_t h3_wf_halfs, h3_wb_halfs;
     // side stream for the weight-gradient GEMMs (off the backward's critical chain), created lazily per device
     int side_dev = -1;
     hipStream_t side = nullptr;
@@ -285,6 +294,140 @@ struct wunet_ctx {
 };
 
 namespace {
+
+int pick_mrep_h3(int mtiles)
+{
+    int best = 2, best_pad = 1 << 30;
+    static const int order[3] = {4, 3, 2};
+    for (int k = 0; k < 3; ++k) {
+        const int pad = round_up(mtiles, order[k]) - mtiles;
+        if (pad < best_pad) { best_pad = pad; best = order[k]; }
+    }
+    return best;
+}
+
+void layout_workspace(wunet_ctx* c)
+{
+    const int B = c->B, T = c->T, ci = c->ci;
+    size_t off = 0, wpk = 0, stats_max = 0, spart_max = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        l.f = plan_conv(B, l.L, l.cout, l.cin, l.taps);
+        l.d = plan_conv(B, l.L, l.cin, l.cout, l.taps);
+        l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
+        if (l.L < 4) { l.f.ksplit = 1; l.d.ksplit = 1; }    // levels of 1-2 samples run the scalar kernels of wunet_tiny.h
+        l.f_rows = l.f.grid_x * WUNET_WAVES;
+        l.f_wpk = wpk;
+        wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
+        if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
+        if (l.f.ksplit > 1 && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
+        if (l.f.ksplit > 1 && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
+        if (l.L < 4 && (size_t)B * l.cout * l.L > spart_max) spart_max = (size_t)B * l.cout * l.L;
+        if (i > 0 && l.d.ksplit > 1 && (size_t)l.d.ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d.ksplit * B * l.cin * l.L;
+        l.z = off; off += align64((size_t)B * l.cout * l.L);
+        l.a = off; off += align64(l.cout);
+        l.s = off; off += align64(l.cout);
+        l.mean = off; off += align64(l.cout);
+        l.rstd = off; off += align64(l.cout);
+        l.xin = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
+    }
+    c->stats_off = off; off += align64(stats_max);
+    c->wpkf_off = off; off += align64(wpk);
+    c->spart_off = off; off += align64(spart_max);
+    // ---- fp16-split path: split activations + forward weight packs live in the forward segment
+    size_t wfh = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        const bool big = c->h3 && l.L >= 256 && l.f.nrep == 4 && l.f.ksplit == 1;
+        l.h3f = big ? 1 : 0;
+        l.h3d = (big && i > 0 && l.d.nrep == 4 && l.d.ksplit == 1) ? 1 : 0;
+        l.xh = l.xl = 0; l.h3f_wpk = l.h3d_wpk = 0;
+        if (l.h3f) {
+            const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
+            l.h3f_mrep = pick_mrep_h3(mt); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
+            l.xh = off; off += align64((size_t)B * c8 * l.L * 4);
+            l.xl = off; off += align64((size_t)B * c8 * l.L * 4);
+            l.h3f_wpk = wfh; wfh += (size_t)l.h3f_mtp * l.h3f_nch * l.taps * 512;
+        }
+    }
+    c->h3_wf_halfs = wfh;
+    c->h3_wf_hi = off; off += align64((wfh + 1) / 2);
+    c->h3_wf_lo = off; off += align64((wfh + 1) / 2);
+    c->fwd_floats = off;
+
+    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        l.g = off; off += align64((size_t)B * l.cout * l.L);
+        l.dx = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);
+        l.k1 = off; off += align64(l.cout);
+        l.k2 = off; off += align64(l.cout);
+        l.k3 = off; off += align64(l.cout);
+        l.d_wpk = wpkb;
+        if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
+        const size_t wg = (size_t)l.w.rows * l.cout * l.cin * l.taps;
+        if (wg > wgpart_max) wgpart_max = wg;
+        long long sp = ((long long)B * l.L) / 4096;
+        l.a_split = (int)(sp < 1 ? 1 : (sp > 64 ? 64 : sp));
+        if ((size_t)l.a_split * l.cout * 2 > bpart_max) bpart_max = (size_t)l.a_split * l.cout * 2;
+    }
+    c->bpart_off = off; off += align64(bpart_max);
+    c->wgpart_off = off; off += align64(wgpart_max);
+    c->wpkb_off = off; off += align64(wpkb);
+    c->gh_off = off; off += align64((size_t)B * T);
+    {
+        long long hb = ((long long)B * T) / 2048;
+        c->head_blocks = (int)(hb < 1 ? 1 : (hb > 1024 ? 1024 : hb));
+    }
+    c->hpart_off = off; off += align64((size_t)c->head_blocks * (ci + 2));
+    // ---- fp16-split data gradient: transposed packs, one shared split g_z buffer, scale slot
+    size_t wbh = 0, gzs = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        if (!l.h3d) continue;
+        const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
+        l.h3d_mrep = pick_mrep_h3(mt); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
+        l.h3d_wpk = wbh; wbh += (size_t)l.h3d_mtp * l.h3d_nch * l.taps * 512;
+        if ((size_t)B * c8 * l.L * 4 > gzs) gzs = (size_t)B * c8 * l.L * 4;
+    }
+    c->h3_wb_halfs = wbh;
+    c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
+    c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
+    c->h3_gz_hi = off; off += align64(gzs);
+    c->h3_gz_lo = off; off += align64(gzs);
+    c->h3_slot = off; off += 64;
+    c->total_floats = off;
+}
+
+// ---- fp16-split helpers
+int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc, int B, int C, int L, hipStream_t st)
+{
+    const int c8 = (C + 7) / 8;
+    const size_t n = (size_t)B * c8 * (L / 4);
+    size_t blocks = (n + WUNET_THREADS - 1) / WUNET_THREADS;
+    if (blocks > 16384) blocks = 16384;
+    WUNET_LAUNCH(split_act_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, hi, lo, sc, B, C, c8, L, ilog2(L));
+    return 0;
+}
+
+int launch_conv_h3(int taps, int mrep, int mblocks, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh, const wunet_half* wl,
+                   const float* bias, const float* sc, float* out, float* stats, int B, int rows, int kch, int nch, int L, hipStream_t st)
+{
+    ConvH3Args a{};
+    a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.out = out; a.stats = stats;
+    a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
+    char pname[96];
+    snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d>", taps, mrep);
+    const double posn = (double)B * L;
+    prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
+    const size_t smem = (size_t)(2 * 4 * 272 + 2 * mrep * 5 * 64) * 16;
+    const dim3 grid((unsigned)((posn + 255) / 256), mblocks);
+    const int rc = wunet_launch_conv_h3(a, taps, mrep, grid, smem, st);
+    prof_end(st);
+    if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d (rc %d)", taps, mrep, rc);
+    return 0;
+}
+
 int ensure_side_stream(wunet_ctx* c)
 {
     int dev = 0;
@@ -334,60 +477,16 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
         }
         l.logL = ilog2(l.L);
     }
-    size_t off = 0, wpk = 0, stats_max = 0, spart_max = 0;
-    for (int i = 0; i < c->NL; ++i) {
-        LayerPlan& l = c->ly[i];
-        l.f = plan_conv(B, l.L, l.cout, l.cin, l.taps);
-        l.d = plan_conv(B, l.L, l.cin, l.cout, l.taps);
-        l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
-        if (l.L < 4) { l.f.ksplit = 1; l.d.ksplit = 1; }    // levels of 1-2 samples run the scalar kernels of wunet_tiny.h
-        l.f_rows = l.f.grid_x * WUNET_WAVES;
-        l.f_wpk = wpk;
-        wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
-        if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
-        if (l.f.ksplit > 1 && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
-        if (l.f.ksplit > 1 && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
-        if (l.L < 4 && (size_t)B * l.cout * l.L > spart_max) spart_max = (size_t)B * l.cout * l.L;
-        if (i > 0 && l.d.ksplit > 1 && (size_t)l.d.ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d.ksplit * B * l.cin * l.L;
-        l.z = off; off += align64((size_t)B * l.cout * l.L);
-        l.a = off; off += align64(l.cout);
-        l.s = off; off += align64(l.cout);
-        l.mean = off; off += align64(l.cout);
-        l.rstd = off; off += align64(l.cout);
-        l.xin = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
-    }
-    c->stats_off = off; off += align64(stats_max);
-    c->wpkf_off = off; off += align64(wpk);
-    c->spart_off = off; off += align64(spart_max);
-    c->fwd_floats = off;
-
-    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0;
-    for (int i = 0; i < c->NL; ++i) {
-        LayerPlan& l = c->ly[i];
-        l.g = off; off += align64((size_t)B * l.cout * l.L);
-        l.dx = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);
-        l.k1 = off; off += align64(l.cout);
-        l.k2 = off; off += align64(l.cout);
-        l.k3 = off; off += align64(l.cout);
-        l.d_wpk = wpkb;
-        if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
-        const size_t wg = (size_t)l.w.rows * l.cout * l.cin * l.taps;
-        if (wg > wgpart_max) wgpart_max = wg;
-        long long sp = ((long long)B * l.L) / 4096;
-        l.a_split = (int)(sp < 1 ? 1 : (sp > 64 ? 64 : sp));
-        if ((size_t)l.a_split * l.cout * 2 > bpart_max) bpart_max = (size_t)l.a_split * l.cout * 2;
-    }
-    c->bpart_off = off; off += align64(bpart_max);
-    c->wgpart_off = off; off += align64(wgpart_max);
-    c->wpkb_off = off; off += align64(wpkb);
-    c->gh_off = off; off += align64((size_t)B * T);
-    {
-        long long hb = ((long long)B * T) / 2048;
-        c->head_blocks = (int)(hb < 1 ? 1 : (hb > 1024 ? 1024 : hb));
-    }
-    c->hpart_off = off; off += align64((size_t)c->head_blocks * (ci + 2));
-    c->total_floats = off;
+    layout_workspace(c);
     *out = c;
+    return WUNET_OK;
+}
+
+int wunet_set_h3(wunet_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(WUNET_E_ARG, "null ctx");
+    ctx->h3 = enable ? 1 : 0;
+    layout_workspace(ctx);          // sizes and offsets change: call before wunet_workspace_bytes
     return WUNET_OK;
 }
 
@@ -438,6 +537,23 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         WUNET_LAUNCH(pack_weights_kernel, dim3(128, c->NL), dim3(WUNET_THREADS), 0, st, tab);
         WUNET_CHECK_LAUNCH();
     }
+    if (c->h3) {
+        PackH3Table tab{};
+        int nd = 0;
+        wunet_half* wh = reinterpret_cast<wunet_half*>(ws + c->h3_wf_hi);
+        wunet_half* wl = reinterpret_cast<wunet_half*>(ws + c->h3_wf_lo);
+        for (int i = 0; i < c->NL; ++i) {
+            const LayerPlan& l = c->ly[i];
+            if (!l.h3f) continue;
+            PackH3Desc& d = tab.d[nd++];
+            d.w = params[4 * i]; d.hi = wh + l.h3f_wpk; d.lo = wl + l.h3f_wpk;
+            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cout; d.kch = l.cin; d.mtiles = l.h3f_mtp; d.nch = l.h3f_nch; d.transposed = 0;
+        }
+        if (nd > 0) {
+            WUNET_LAUNCH(pack_h3_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_CHECK_LAUNCH();
+        }
+    }
     for (int i = 0; i < c->NL; ++i) {
         const LayerPlan& l = c->ly[i];
         // 2a. materialise the conv input: BN scale/shift + LeakyReLU + decimation, or + x2 upsample + skip concat
@@ -473,7 +589,18 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         // 2b. conv (+ bias, + per-wave BN statistics partials) on the matrix cores
         const bool tiny = l.L < 4;
         const bool split = l.f.ksplit > 1 || tiny;      // both leave a bias-free result in the split buffer
-        if (tiny) {
+        if (l.h3f) {
+            // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
+            wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);
+            wunet_half* xl = reinterpret_cast<wunet_half*>(ws + l.xl);
+            launch_split(xin, xh, xl, nullptr, c->B, l.cin, l.L, st);
+            WUNET_CHECK_LAUNCH();
+            int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp / l.h3f_mrep, xh, xl,
+                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
+                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], nullptr,
+                                    ws + l.z, training ? ws + c->stats_off : nullptr, c->B, l.cout, l.cin, l.h3f_nch, l.L, st);
+            if (rc) return rc;
+        } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;
             WUNET_LAUNCH(tiny_conv_kernel, dim3((unsigned)((no + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st,
                          xin, params[4 * i], ws + c->spart_off, c->B, l.cin, l.cout, l.L, l.logL, l.taps, 0);
@@ -553,6 +680,24 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         if (nd > 0) {
             WUNET_LAUNCH(pack_weights_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
             WUNET_CHECK_LAUNCH();
+        }
+        if (c->h3) {
+            PackH3Table t3{};
+            int n3 = 0;
+            wunet_half* wh = reinterpret_cast<wunet_half*>(ws + c->h3_wb_hi);
+            wunet_half* wl = reinterpret_cast<wunet_half*>(ws + c->h3_wb_lo);
+            for (int i = 1; i < NL; ++i) {
+                const LayerPlan& l = c->ly[i];
+                if (!l.h3d) continue;
+                PackH3Desc& d = t3.d[n3++];
+                d.w = params[4 * i]; d.hi = wh + l.h3d_wpk; d.lo = wl + l.h3d_wpk;
+                d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
+            }
+            if (n3 > 0) {
+                WUNET_LAUNCH(pack_h3_kernel, dim3(128, n3), dim3(WUNET_THREADS), 0, st, t3);
+                WUNET_CHECK_LAUNCH();
+            }
+            hipMemsetAsync(ws + c->h3_slot, 0, 64 * sizeof(float), st);      // amax word of the gradient scale
         }
         // head backward: gh = gout * tanh', d wh, d bh
         const LayerPlan& l = c->ly[NL - 1];
@@ -640,7 +785,26 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             }
         }
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
-        if (i > 0 && tiny) {
+        if (i > 0 && l.h3d) {
+            // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
+            unsigned* amax = reinterpret_cast<unsigned*>(ws + c->h3_slot);
+            float* sc = ws + c->h3_slot + 2;
+            const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
+            size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
+            if (blocks > 2048) blocks = 2048;
+            WUNET_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), n4, amax);
+            WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, amax, sc);
+            wunet_half* gh = reinterpret_cast<wunet_half*>(ws + c->h3_gz_hi);
+            wunet_half* gl = reinterpret_cast<wunet_half*>(ws + c->h3_gz_lo);
+            launch_split(ws + l.g, gh, gl, sc, c->B, l.cout, l.L, st);
+            WUNET_CHECK_LAUNCH();
+            int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp / l.h3d_mrep, gh, gl,
+                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
+                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
+                                    ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st);
+            if (rc) return rc;
+            WUNET_CHECK_LAUNCH();
+        } else if (i > 0 && tiny) {
             const size_t nd = (size_t)c->B * l.cin * l.L;
             WUNET_LAUNCH(tiny_conv_kernel, dim3((unsigned)((nd + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st,
                          (const float*)(ws + l.g), params[4 * i], ws + l.dx, c->B, l.cout, l.cin, l.L, l.logL, l.taps, 1);

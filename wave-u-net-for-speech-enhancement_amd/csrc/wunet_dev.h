@@ -26,7 +26,32 @@ __device__ __forceinline__ float wunet_shfl_xor(float v, int mask) { return __sh
 __device__ __forceinline__ wunet_f4 wunet_ld4(const float* p) { return *reinterpret_cast<const wunet_f4*>(p); }
 __device__ __forceinline__ void wunet_st4(float* p, wunet_f4 v) { *reinterpret_cast<wunet_f4*>(p) = v; }
 __device__ __forceinline__ wunet_f4 wunet_sel4(bool ok, wunet_f4 v) { return ok ? v : wunet_f4{0.f, 0.f, 0.f, 0.f}; }
+
+// ---- fp16 split ("h3") arithmetic: x = hi + lo with hi, lo fp16 (22 significant bits together); a product is
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation - fp32-grade accuracy at 3 passes of the
+// 2.5 PF matrix pipe.  Halfs travel as raw 16-bit words.
+typedef _Float16 wunet_h8 __attribute__((ext_vector_type(8)));     // 8 halfs = 16 bytes = one MFMA operand
+typedef unsigned short wunet_half;                                  // storage type in global memory / LDS
+__device__ __forceinline__ wunet_half wunet_f2h(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ float wunet_h2f(wunet_half h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ wunet_h8 wunet_ldh8(const wunet_half* p) { return *reinterpret_cast<const wunet_h8*>(p); }
+__device__ __forceinline__ void wunet_sth8(wunet_half* p, wunet_h8 v) { *reinterpret_cast<wunet_h8*>(p) = v; }
+__device__ __forceinline__ wunet_h8 wunet_selh8(bool ok, wunet_h8 v) { return ok ? v : wunet_h8{0, 0, 0, 0, 0, 0, 0, 0}; }
+__device__ __forceinline__ void wunet_put_half(wunet_h8& v, int e, wunet_half h) { v[e] = __builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ unsigned wunet_fbits(float f) { return __float_as_uint(f); }
+// v_mfma_f32_16x16x32_f16: lane l holds A[i=l&15][k=(l>>4)*8..+7], B[k=(l>>4)*8..+7][j=l&15]; D as for 16x16x4.
+__device__ __forceinline__ wunet_f4 wunet_mfma16h(wunet_h8 a, wunet_h8 b, wunet_f4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
 #endif
+
+// hi/lo fp16 split of s*x (s a power of two chosen so that |s*x| stays far below 65504)
+__device__ __forceinline__ void wunet_split_h(float x, wunet_half& hi, wunet_half& lo)
+{
+    hi = wunet_f2h(x);
+    lo = wunet_f2h(x - wunet_h2f(hi));
+}
 
 #define WUNET_THREADS 256
 #define WUNET_WAVES 4

@@ -1,0 +1,119 @@
+// Elementwise side of the fp16-split ("h3") path (see wunet_h3.h): gradient scale, fp32 -> hi/lo split into the
+// channel-group-major layout, weight pack.  Included by the host translation unit only.
+#pragma once
+#include "wunet_elementwise.h"
+#include "wunet_h3.h"
+
+// ---------------------------------------------------------------------------- scale of a gradient tensor
+// amax word holds max |x| as float bits (atomicMax on the unsigned pattern); sc[0] = 2^k with 2^k*amax in [512, 1024),
+// sc[1] = 2^-k.  An all-zero tensor gets 1.
+__global__ __launch_bounds__(WUNET_THREADS) void absmax_kernel(const float* x, size_t n4, unsigned* amax)
+{
+    __shared__ unsigned red[WUNET_THREADS];
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const wunet_f4 v = wunet_ld4(x + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned u = wunet_fbits(fabsf(v[j]));
+            m = u > m ? u : m;
+        }
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicMax(amax, red[0]);
+}
+
+__global__ void scale_from_amax_kernel(unsigned* amax, float* sc)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const unsigned u = *amax;
+        const int e = (int)((u >> 23) & 0xffu) - 127;                  // floor(log2(amax))
+        float s = 1.0f, inv = 1.0f;
+        if (u != 0 && u < 0x7f800000u) {
+            int k = 9 - e;                                             // 2^k * amax in [2^9, 2^10)
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            s = ldexpf(1.0f, k);
+            inv = ldexpf(1.0f, -k);
+        }
+        sc[0] = s;
+        sc[1] = inv;
+        *amax = 0;                                                     // ready for the next use
+    }
+}
+
+// fp32 [B][C][L]  ->  hi / lo [B][C8][L][8] halfs of sc[0]*x (sc == nullptr: unscaled).  One thread per
+// (channel group, 4 samples): 8 float4 loads, 4+4 16-byte stores.
+__global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x, wunet_half* hi, wunet_half* lo, const float* sc,
+                                                                   int B, int C, int C8, int L, int logL)
+{
+    const int l4n = L >> 2;
+    const float s = sc ? sc[0] : 1.0f;
+    const size_t total = (size_t)B * C8 * l4n;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const int l4 = (int)(i & (size_t)(l4n - 1));
+        const size_t row = i >> (logL - 2);
+        const int b = (int)(row / (size_t)C8), c8 = (int)(row - (size_t)b * C8);
+        wunet_f4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            const bool ok = c < C;
+            v[e] = wunet_sel4(ok, wunet_ld4(x + ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4));
+        }
+        wunet_half* ph = hi + (row * L + 4 * (size_t)l4) * 8;
+        wunet_half* pl = lo + (row * L + 4 * (size_t)l4) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wunet_h8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wunet_half a, d;
+                wunet_split_h(s * v[e][j], a, d);
+                wunet_put_half(h, e, a);
+                wunet_put_half(l, e, d);
+            }
+            wunet_sth8(ph + 8 * j, h);
+            wunet_sth8(pl + 8 * j, l);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- weight pack
+// dst[mt][chunk][tap][q][i][e] = W(row = mt*16+i, k-channel = chunk*32+q*8+e, tap); forward: W = w[row][kch][tap];
+// data gradient (transposed): W = w[kch][row][TAPS-1-tap].  hi and lo arrays.
+struct PackH3Desc {
+    const float* w;
+    wunet_half* hi;
+    wunet_half* lo;
+    int Cout, Cin, taps;   // shape of w
+    int rows, kch;         // GEMM rows / K channels (Cout,Cin forward; Cin,Cout transposed)
+    int mtiles, nch;       // padded m-tiles, chunks of 32 K channels
+    int transposed;
+};
+struct PackH3Table { PackH3Desc d[WUNET_MAX_CONV_LAYERS]; };
+
+__global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
+{
+    const PackH3Desc& d = tab.d[blockIdx.y];
+    const int total = d.mtiles * d.nch * d.taps * 512;
+    for (int idx = blockIdx.x * WUNET_THREADS + threadIdx.x; idx < total; idx += gridDim.x * WUNET_THREADS) {
+        const int e = idx & 7, i = (idx >> 3) & 15, q = (idx >> 7) & 3;
+        int r = idx >> 9;
+        const int t = r % d.taps; r /= d.taps;
+        const int ch = r % d.nch, mt = r / d.nch;
+        const int row = mt * 16 + i, k = ch * 32 + q * 8 + e;
+        float v = 0.0f;
+        if (row < d.rows && k < d.kch)
+            v = d.transposed ? d.w[((size_t)k * d.Cin + row) * d.taps + (d.taps - 1 - t)] : d.w[((size_t)row * d.Cin + k) * d.taps + t];
+        wunet_half a, b;
+        wunet_split_h(v, a, b);
+        d.hi[idx] = a;
+        d.lo[idx] = b;
+    }
+}
+

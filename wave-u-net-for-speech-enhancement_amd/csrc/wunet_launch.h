@@ -20,3 +20,6 @@ WUNET_DECL_CONV(15);
 WUNET_DECL_CONV(5);
 WUNET_DECL_WGRAD(15);
 WUNET_DECL_WGRAD(5);
+
+struct ConvH3Args;
+int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, dim3 grid, size_t smem, hipStream_t st);

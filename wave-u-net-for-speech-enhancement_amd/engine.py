@@ -2,6 +2,7 @@
 and enqueues the HIP path on torch's current stream.  PyTorch is plumbing here (device memory,
 streams); every arithmetic kernel lives in csrc/."""
 import ctypes
+import os
 import threading
 
 import torch
@@ -20,9 +21,11 @@ class Engine:
     suite can drive the same host logic against the emulator build with CPU tensors; product code
     never passes them."""
 
-    def __init__(self, lib=None, host_memory=False):
+    def __init__(self, lib=None, host_memory=False, h3=None):
         self.lib = lib if lib is not None else _lib.load_hip()
         self.host_memory = host_memory
+        # fp16-split GEMMs for the large levels (see include/wunet_hip.h: wunet_set_h3); WUNET_H3=1 turns it on
+        self.h3 = bool(int(os.environ.get("WUNET_H3", "0"))) if h3 is None else bool(h3)
         self._ctx = {}
         self._lock = threading.Lock()
 
@@ -38,6 +41,8 @@ class Engine:
             if h is None:
                 h = ctypes.c_void_p()
                 self._check(self.lib.wunet_create(n_layers, ci, batch, length, ctypes.byref(h)))
+                if self.h3:
+                    self._check(self.lib.wunet_set_h3(h, 1))
                 self._ctx[key] = h
         return h
 
