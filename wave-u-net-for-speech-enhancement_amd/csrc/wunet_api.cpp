@@ -750,13 +750,15 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
+            if (i > 0 && l.h3d && blocks > 512) blocks = 512;     // one atomicMax per block on ONE word: keep them few
             if (tiny)
                 WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
                              (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
                              (size_t)c->B * l.cout * l.L, ws + l.g);
             else
             WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
+                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g,   // in place
+                         (i > 0 && l.h3d) ? reinterpret_cast<unsigned*>(ws + c->h3_slot) : (unsigned*)nullptr);
             WUNET_CHECK_LAUNCH();
         }
         // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
@@ -789,10 +791,6 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
             unsigned* amax = reinterpret_cast<unsigned*>(ws + c->h3_slot);
             float* sc = ws + c->h3_slot + 2;
-            const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
-            size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
-            if (blocks > 2048) blocks = 2048;
-            WUNET_LAUNCH(absmax_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), n4, amax);
             WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, amax, sc);
             wunet_half* gh = reinterpret_cast<wunet_half*>(ws + c->h3_gz_hi);
             wunet_half* gl = reinterpret_cast<wunet_half*>(ws + c->h3_gz_lo);

@@ -504,8 +504,11 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, i
 // g_z = k1*g + k2*z + k3 (BatchNorm backward folded to three per-channel coefficients), materialised once
 // per layer for its data-gradient and weight-gradient GEMMs
 __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
-                                                                        const float* k3, int C, int logL, size_t n4, float* gz)
+                                                                        const float* k3, int C, int logL, size_t n4, float* gz, unsigned* amax)
 {
+    // amax != nullptr: also track max |g_z| (float bits, atomicMax) - the power-of-two scale of the fp16-split path
+    __shared__ unsigned red[WUNET_THREADS];
+    unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int c = (int)((i >> (logL - 2)) % (size_t)C);
         const float a = k1[c], b = k2[c], d = k3[c];
@@ -514,6 +517,20 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const flo
         o.x = a * gv.x + b * zv.x + d; o.y = a * gv.y + b * zv.y + d;
         o.z = a * gv.z + b * zv.z + d; o.w = a * gv.w + b * zv.w + d;
         reinterpret_cast<float4*>(gz)[i] = o;
+        if (amax) {
+            const float mx = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+            const unsigned u = wunet_fbits(mx);
+            m = u > m ? u : m;
+        }
+    }
+    if (amax) {
+        red[threadIdx.x] = m;
+        __syncthreads();
+        for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) atomicMax(amax, red[0]);
     }
 }
 
