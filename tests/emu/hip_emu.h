@@ -94,6 +94,7 @@ inline float wunet_h2f(wunet_half h)
 struct wunet_h8 { wunet_half v[8]; wunet_half& operator[](int i) { return v[i]; } const wunet_half& operator[](int i) const { return v[i]; } };
 inline wunet_h8 wunet_ldh8(const wunet_half* p) { wunet_h8 r; std::memcpy(r.v, p, 16); return r; }
 inline void wunet_sth8(wunet_half* p, wunet_h8 v) { std::memcpy(p, v.v, 16); }
+inline void wunet_sth4(wunet_half* p, const wunet_half (&h)[4]) { std::memcpy(p, h, 8); }
 inline void wunet_put_half(wunet_h8& v, int e, wunet_half h) { v.v[e] = h; }
 inline unsigned wunet_fbits(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 inline unsigned atomicMax(unsigned* p, unsigned v)
@@ -103,6 +104,16 @@ inline unsigned atomicMax(unsigned* p, unsigned v)
     return old;
 }
 inline wunet_h8 wunet_selh8(bool ok, wunet_h8 v) { return ok ? v : wunet_h8{{0, 0, 0, 0, 0, 0, 0, 0}}; }
+
+template <int O>
+inline wunet_h8 wunet_funnel(const wunet_h8 (&p)[3])
+{
+    wunet_half all[24];
+    for (int m = 0; m < 3; ++m) std::memcpy(all + 8 * m, p[m].v, 16);
+    wunet_h8 r;
+    for (int e = 0; e < 8; ++e) r.v[e] = all[O + e];
+    return r;
+}
 
 inline wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
 {

@@ -272,6 +272,7 @@ struct LayerPlan {
     // fp16-split path (large levels only)
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
+    int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps;   // weight gradient uses wgrad_h3_kernel
     size_t xh, xl;                // split activated input (float offsets)
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
 };
@@ -365,7 +366,22 @@ void layout_workspace(wunet_ctx* c)
         l.k3 = off; off += align64(l.cout);
         l.d_wpk = wpkb;
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
-        const size_t wg = (size_t)l.w.rows * l.cout * l.cin * l.taps;
+        l.h3w = (l.h3d && l.cin >= 16 && !getenv("WUNET_NO_H3W")) ? 1 : 0;
+        if (l.h3w) {
+            const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
+            l.h3w_mrep = pick_mrep_h3(mt);
+            if (l.h3w_mrep == 4 && round_up(mt, 3) == round_up(mt, 4)) l.h3w_mrep = 3;       // same padding: fewer registers
+            l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
+            l.h3w_nblocks = (l.cin + cib - 1) / cib;
+            const long long chunks = (long long)B * l.L / 128;
+            const long long slots = 256LL * (l.h3w_mrep <= 3 ? 2 : 1);
+            long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
+            if (ks < 1) ks = 1;
+            if (ks > chunks) ks = chunks;
+            l.h3w_cps = (int)((chunks + ks - 1) / ks);
+            l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
+        }
+        const size_t wg = (size_t)(l.h3w ? l.h3w_ksplit : l.w.rows) * l.cout * l.cin * l.taps;
         if (wg > wgpart_max) wgpart_max = wg;
         long long sp = ((long long)B * l.L) / 4096;
         l.a_split = (int)(sp < 1 ? 1 : (sp > 64 ? 64 : sp));
@@ -395,7 +411,7 @@ void layout_workspace(wunet_ctx* c)
     c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
     c->h3_gz_hi = off; off += align64(gzs);
     c->h3_gz_lo = off; off += align64(gzs);
-    c->h3_slot = off; off += 64;
+    c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // amax word, then {scale, 1/scale} per layer
     c->total_floats = off;
 }
 
@@ -425,6 +441,24 @@ int launch_conv_h3(int taps, int mrep, int mblocks, const wunet_half* xh, const 
     const int rc = wunet_launch_conv_h3(a, taps, mrep, grid, smem, st);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d (rc %d)", taps, mrep, rc);
+    return 0;
+}
+
+int launch_wgrad_h3(const LayerPlan& l, const float* x, const float* g, const float* sc, float* part, int B, hipStream_t st)
+{
+    WgradH3Args a{};
+    a.x = x; a.g = g; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout; a.L = l.L; a.logL = l.logL;
+    a.chunks_per_split = l.h3w_cps;
+    char pname[96];
+    snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
+    const double posn = (double)B * l.L;
+    prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
+    const int cib = l.taps == 15 ? 32 : 64;
+    const size_t smem = ((size_t)(2 * l.h3w_mrep * 16 + 2 * cib) * 144 + 16) * 2;
+    const dim3 grid(l.h3w_ksplit, l.h3w_nblocks, l.h3w_mblocks);
+    const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, grid, smem, st);
+    prof_end(st);
+    if (rc != 0) return fail(WUNET_E_ARG, "no wgrad_h3 kernel for taps=%d mrep=%d (rc %d)", l.taps, l.h3w_mrep, rc);
     return 0;
 }
 
@@ -697,7 +731,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 WUNET_LAUNCH(pack_h3_kernel, dim3(128, n3), dim3(WUNET_THREADS), 0, st, t3);
                 WUNET_CHECK_LAUNCH();
             }
-            hipMemsetAsync(ws + c->h3_slot, 0, 64 * sizeof(float), st);      // amax word of the gradient scale
+            hipMemsetAsync(ws + c->h3_slot, 0, 8 * sizeof(float), st);      // amax word of the gradient scale
         }
         // head backward: gh = gout * tanh', d wh, d bh
         const LayerPlan& l = c->ly[NL - 1];
@@ -760,6 +794,10 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                          (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g,   // in place
                          (i > 0 && l.h3d) ? reinterpret_cast<unsigned*>(ws + c->h3_slot) : (unsigned*)nullptr);
             WUNET_CHECK_LAUNCH();
+            if (i > 0 && l.h3d) {      // power-of-two scale of g_z for the fp16-split GEMMs (kept per layer: the side stream reads it late)
+                WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(ws + c->h3_slot), ws + c->h3_slot + 8 + 4 * i);
+                WUNET_CHECK_LAUNCH();
+            }
         }
         // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
         //      + deterministic reduce
@@ -775,23 +813,25 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                              (const float*)(ws + l.g), xin, grads[4 * i], c->B, l.cin, l.cout, l.L, l.taps);
                 WUNET_CHECK_LAUNCH();
             } else {
-                const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
-                int rc = launch_wgrad_any(l.taps, w, l.w, sd);
+                int rc;
+                if (l.h3w) rc = launch_wgrad_h3(l, xin, ws + l.g, ws + c->h3_slot + 8 + 4 * i, ws + c->wgpart_off, c->B, sd);
+                else {
+                    const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
+                    rc = launch_wgrad_any(l.taps, w, l.w, sd);
+                }
                 if (rc) return rc;
                 WUNET_CHECK_LAUNCH();
                 size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (blocks > 2048) blocks = 2048;
                 WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
-                             (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
+                             (const float*)(ws + c->wgpart_off), l.h3w ? l.h3w_ksplit : l.w.rows, nw, grads[4 * i]);
                 WUNET_CHECK_LAUNCH();
             }
         }
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
         if (i > 0 && l.h3d) {
             // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
-            unsigned* amax = reinterpret_cast<unsigned*>(ws + c->h3_slot);
-            float* sc = ws + c->h3_slot + 2;
-            WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, amax, sc);
+            float* sc = ws + c->h3_slot + 8 + 4 * i;
             wunet_half* gh = reinterpret_cast<wunet_half*>(ws + c->h3_gz_hi);
             wunet_half* gl = reinterpret_cast<wunet_half*>(ws + c->h3_gz_lo);
             launch_split(ws + l.g, gh, gl, sc, c->B, l.cout, l.L, st);

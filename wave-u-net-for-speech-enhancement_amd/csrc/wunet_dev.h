@@ -36,6 +36,11 @@ __device__ __forceinline__ wunet_half wunet_f2h(float x) { return __builtin_bit_
 __device__ __forceinline__ float wunet_h2f(wunet_half h) { return (float)__builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ wunet_h8 wunet_ldh8(const wunet_half* p) { return *reinterpret_cast<const wunet_h8*>(p); }
 __device__ __forceinline__ void wunet_sth8(wunet_half* p, wunet_h8 v) { *reinterpret_cast<wunet_h8*>(p) = v; }
+__device__ __forceinline__ void wunet_sth4(wunet_half* p, const wunet_half (&h)[4])
+{
+    typedef unsigned wunet_u2 __attribute__((ext_vector_type(2)));
+    *reinterpret_cast<wunet_u2*>(p) = wunet_u2{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)};
+}
 __device__ __forceinline__ wunet_h8 wunet_selh8(bool ok, wunet_h8 v) { return ok ? v : wunet_h8{0, 0, 0, 0, 0, 0, 0, 0}; }
 __device__ __forceinline__ void wunet_put_half(wunet_h8& v, int e, wunet_half h) { v[e] = __builtin_bit_cast(_Float16, h); }
 __device__ __forceinline__ unsigned wunet_fbits(float f) { return __float_as_uint(f); }
@@ -43,6 +48,24 @@ __device__ __forceinline__ unsigned wunet_fbits(float f) { return __float_as_uin
 __device__ __forceinline__ wunet_f4 wunet_mfma16h(wunet_h8 a, wunet_h8 b, wunet_f4 c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// 8 halfs starting O halfs into the 24 halfs p[0] | p[1] | p[2] (O in 0..16, compile time): the tap shift of the
+// weight-gradient B operand, done with v_alignbit on aligned 16-byte LDS pieces
+typedef unsigned wunet_u4 __attribute__((ext_vector_type(4)));
+template <int O>
+__device__ __forceinline__ wunet_h8 wunet_funnel(const wunet_h8 (&p)[3])
+{
+    const wunet_u4 a = __builtin_bit_cast(wunet_u4, p[0]), b = __builtin_bit_cast(wunet_u4, p[1]), c = __builtin_bit_cast(wunet_u4, p[2]);
+    const unsigned d[13] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3], 0u};
+    constexpr int w = O / 2;
+    wunet_u4 r;
+    if (O & 1) {
+        r[0] = __builtin_amdgcn_alignbit(d[w + 1], d[w], 16); r[1] = __builtin_amdgcn_alignbit(d[w + 2], d[w + 1], 16);
+        r[2] = __builtin_amdgcn_alignbit(d[w + 3], d[w + 2], 16); r[3] = __builtin_amdgcn_alignbit(d[w + 4], d[w + 3], 16);
+    } else {
+        r[0] = d[w]; r[1] = d[w + 1]; r[2] = d[w + 2]; r[3] = d[w + 3];
+    }
+    return __builtin_bit_cast(wunet_h8, r);
 }
 #endif
 

@@ -176,3 +176,154 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
         }
     }
 }
+
+// ---------------------------------------------------------------------------- weight gradient
+// dW[co][ci][t] = sum_{b,p} g_z[b][co][p] * x[b][ci][p + t - PAD] as a GEMM over positions (K) on the fp16 split:
+// A = g_z (rows co, K = 8 consecutive positions per lane), B = x with one n-tile = 16 input channels at ONE tap, so the
+// tap shift is uniform per MFMA.  Both operands are staged from the fp32 activations ([B][C][L], positions
+// contiguous) and split into hi/lo on the way into LDS (ds_write_b64 of 4 halfs); fragments are aligned ds_read_b128
+// of a [row][144] half image (row stride = 2 sixteen-byte slots mod 16: conflict free), and the tap shift is a
+// compile-time funnel shift (v_alignbit) over three consecutive pieces held in registers.
+//   TAPS = 15: block = M_REP*16 co x 32 ci; wave = (ci group, tap half of 8)  -> M_REP*8 accumulator tiles
+//   TAPS =  5: block = M_REP*16 co x 64 ci; wave = ci group, all 5 taps        -> M_REP*5 accumulator tiles
+// Split-K over gridDim.x like wgrad_mfma_kernel: partial dW [gridDim.x][Cout][Cin][TAPS], reduced by wgrad_reduce_kernel.
+struct WgradH3Args {
+    const float* x;      // [B][Cin][L]
+    const float* g;      // [B][Cout][L]  g_z
+    const float* sc;     // {scale, 1/scale} of g_z
+    float* part;
+    int B, Cin, Cout, L, logL, chunks_per_split;
+};
+
+template <int TAPS, int M_REP>
+__global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
+{
+    constexpr int PAD = TAPS / 2;
+    constexpr int TP = 128, ROW = 144;
+    constexpr int WG = TAPS == 15 ? 2 : 4;          // ci groups of 16 per block
+    constexpr int TW = TAPS == 15 ? 8 : 5;          // taps per wave
+    constexpr int OB = TAPS == 15 ? 1 : 8 - PAD;    // funnel offset of the wave's first tap
+    constexpr int CIB = WG * 16, GROWS = M_REP * 16;
+    constexpr int GIT = GROWS * (TP / 4) / WUNET_THREADS;                      // 2 * M_REP float4 per thread
+    constexpr int XF4 = CIB * (ROW / 4);
+    constexpr int XIT = (XF4 + WUNET_THREADS - 1) / WUNET_THREADS;
+    WUNET_DYN_SMEM(smem);
+    wunet_half* gh = reinterpret_cast<wunet_half*>(smem);                      // [GROWS][ROW]
+    wunet_half* gl = gh + GROWS * ROW;
+    wunet_half* xh = gl + GROWS * ROW;                                         // [CIB][ROW]
+    wunet_half* xl = xh + CIB * ROW;                                           // (+16 halfs of slack behind it)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
+    const int grp = TAPS == 15 ? wave >> 1 : wave;
+    const int th = TAPS == 15 ? wave & 1 : 0;
+    const int t0 = th * 8;
+    const int co0 = blockIdx.z * GROWS, ci0 = blockIdx.y * CIB;
+    const int L = A.L;
+    const long long nchunks = ((long long)A.B * L) / TP;
+    const long long kbeg = (long long)blockIdx.x * A.chunks_per_split;
+    long long kend = kbeg + A.chunks_per_split;
+    if (kend > nchunks) kend = nchunks;
+    const float s = A.sc[0];
+
+    wunet_f4 acc[M_REP][TW];
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) acc[mt][tw] = wunet_f4{0.f, 0.f, 0.f, 0.f};
+
+    wunet_f4 greg[GIT], xreg[XIT];
+#define WUNET_WH3_PREFETCH(K_)                                                                                    \
+    {                                                                                                             \
+        const long long n0_ = (K_) * TP;                                                                          \
+        const int b_ = (int)(n0_ >> A.logL), l0_ = (int)(n0_ & (L - 1));                                          \
+        _Pragma("unroll") for (int it = 0; it < GIT; ++it) {                                                      \
+            const int f_ = tid + it * WUNET_THREADS;                                                              \
+            const int co_ = co0 + (f_ >> 5);                                                                      \
+            const bool ok_ = co_ < A.Cout;                                                                        \
+            greg[it] = wunet_ld4(A.g + (ok_ ? ((size_t)b_ * A.Cout + co_) * L + l0_ + (f_ & 31) * 4 : 0));        \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
+            const int f_ = tid + it * WUNET_THREADS;                                                              \
+            const int r_ = f_ / (ROW / 4), c4_ = f_ - r_ * (ROW / 4);                                             \
+            const int l_ = l0_ - 8 + c4_ * 4;                                                                     \
+            const bool ok_ = f_ < XF4 && ci0 + r_ < A.Cin && l_ >= 0 && l_ < L;                                   \
+            xreg[it] = wunet_ld4(A.x + (ok_ ? ((size_t)b_ * A.Cin + ci0 + r_) * L + l_ : 0));                     \
+        }                                                                                                         \
+    }
+    if (kbeg < kend) WUNET_WH3_PREFETCH(kbeg)
+
+    for (long long k = kbeg; k < kend; ++k) {
+        const int l0 = (int)((k * TP) & (L - 1));
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < GIT; ++it) {
+            const int f = tid + it * WUNET_THREADS;
+            const bool ok = co0 + (f >> 5) < A.Cout;
+            const wunet_f4 v = wunet_sel4(ok, greg[it]);
+            wunet_half h[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wunet_split_h(v[e] * s, h[e], lo[e]);
+            const int o = (f >> 5) * ROW + (f & 31) * 4;
+            wunet_sth4(gh + o, h);
+            wunet_sth4(gl + o, lo);
+        }
+#pragma unroll
+        for (int it = 0; it < XIT; ++it) {
+            const int f = tid + it * WUNET_THREADS;
+            const int r = f / (ROW / 4), c4 = f - r * (ROW / 4);
+            const int l = l0 - 8 + c4 * 4;
+            const bool ok = ci0 + r < A.Cin && l >= 0 && l < L;
+            const wunet_f4 v = wunet_sel4(ok, xreg[it]);
+            wunet_half h[4], lo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wunet_split_h(v[e], h[e], lo[e]);
+            if (f < XF4) {
+                wunet_sth4(xh + r * ROW + c4 * 4, h);
+                wunet_sth4(xl + r * ROW + c4 * 4, lo);
+            }
+        }
+        __syncthreads();
+        if (k + 1 < kend) WUNET_WH3_PREFETCH(k + 1)
+#pragma unroll
+        for (int ks = 0; ks < TP / 32; ++ks) {
+            wunet_h8 ah[M_REP], al[M_REP], ph[3], pl[3];
+#pragma unroll
+            for (int mt = 0; mt < M_REP; ++mt) {
+                ah[mt] = wunet_ldh8(gh + (mt * 16 + i16) * ROW + ks * 32 + q * 8);
+                al[mt] = wunet_ldh8(gl + (mt * 16 + i16) * ROW + ks * 32 + q * 8);
+            }
+            const int xb = (grp * 16 + i16) * ROW + ks * 32 + q * 8 + t0;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+                ph[m] = wunet_ldh8(xh + xb + m * 8);
+                pl[m] = wunet_ldh8(xl + xb + m * 8);
+            }
+#define WUNET_WH3_TAP(TW_)                                                                                         \
+            if (TW_ < TW && t0 + TW_ < TAPS) {                                                                     \
+                const wunet_h8 bh_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(ph);                                  \
+                const wunet_h8 bl_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(pl);                                  \
+                _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                             \
+                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(al[mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]);         \
+                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[mt], bl_, acc[mt][TW_ < TW ? TW_ : 0]);         \
+                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]);         \
+                }                                                                                                  \
+            }
+            WUNET_WH3_TAP(0) WUNET_WH3_TAP(1) WUNET_WH3_TAP(2) WUNET_WH3_TAP(3)
+            WUNET_WH3_TAP(4) WUNET_WH3_TAP(5) WUNET_WH3_TAP(6) WUNET_WH3_TAP(7)
+#undef WUNET_WH3_TAP
+        }
+    }
+#undef WUNET_WH3_PREFETCH
+
+    const float inv = A.sc[1];
+    float* part = A.part + (size_t)blockIdx.x * A.Cout * A.Cin * TAPS;
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + mt * 16 + q * 4 + r, ci = ci0 + grp * 16 + i16, tap = t0 + tw;
+                if (co < A.Cout && ci < A.Cin && tap < TAPS) part[((size_t)co * A.Cin + ci) * TAPS + tap] = acc[mt][tw][r] * inv;
+            }
+}
