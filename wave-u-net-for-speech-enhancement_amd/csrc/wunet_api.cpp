@@ -274,6 +274,7 @@ struct LayerPlan {
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps;   // weight gradient uses wgrad_h3_kernel
     size_t xh, xl;                // split activated input (float offsets)
+    size_t gzh, gzl;              // split scaled g_z (float offsets)
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
 };
 
@@ -286,7 +287,7 @@ struct wunet_ctx {
     size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
     int head_blocks;
     int h3 = 0;                   // fp16-split GEMMs enabled for the large levels
-    size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_gz_hi, h3_gz_lo, h3_slot;   // float offsets
+    size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_slot;   // float offsets
     size_t h3_wf_halfs, h3_wb_halfs;
     // side stream for the weight-gradient GEMMs (off the backward's critical chain), created lazily per device
     int side_dev = -1;
@@ -299,10 +300,12 @@ namespace {
 int pick_mrep_h3(int mtiles)
 {
     int best = 2, best_pad = 1 << 30;
-    static const int order[3] = {4, 3, 2};
-    for (int k = 0; k < 3; ++k) {
-        const int pad = round_up(mtiles, order[k]) - mtiles;
-        if (pad < best_pad) { best_pad = pad; best = order[k]; }
+    const char* ord = getenv("WUNET_H3_ORDER");       // A/B switch for measurements
+    if (!ord) ord = "23";                             // ties go to the smaller tile: two blocks per CU hide the staging latency
+    for (const char* p = ord; *p; ++p) {
+        const int m = *p - '0';
+        const int pad = round_up(mtiles, m) - mtiles;
+        if (pad < best_pad) { best_pad = pad; best = m; }
     }
     return best;
 }
@@ -404,13 +407,13 @@ void layout_workspace(wunet_ctx* c)
         const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
         l.h3d_mrep = pick_mrep_h3(mt); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
         l.h3d_wpk = wbh; wbh += (size_t)l.h3d_mtp * l.h3d_nch * l.taps * 512;
-        if ((size_t)B * c8 * l.L * 4 > gzs) gzs = (size_t)B * c8 * l.L * 4;
+        l.gzh = off; off += align64((size_t)B * c8 * l.L * 4);      // per layer: the side stream reads it late
+        l.gzl = off; off += align64((size_t)B * c8 * l.L * 4);
     }
     c->h3_wb_halfs = wbh;
     c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
     c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
-    c->h3_gz_hi = off; off += align64(gzs);
-    c->h3_gz_lo = off; off += align64(gzs);
+    (void)gzs;
     c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // amax word, then {scale, 1/scale} per layer
     c->total_floats = off;
 }
@@ -444,17 +447,19 @@ int launch_conv_h3(int taps, int mrep, int mblocks, const wunet_half* xh, const 
     return 0;
 }
 
-int launch_wgrad_h3(const LayerPlan& l, const float* x, const float* g, const float* sc, float* part, int B, hipStream_t st)
+int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
+                    const float* sc, float* part, int B, hipStream_t st)
 {
     WgradH3Args a{};
-    a.x = x; a.g = g; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout; a.L = l.L; a.logL = l.logL;
+    a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
+    a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
     a.chunks_per_split = l.h3w_cps;
     char pname[96];
     snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
     const double posn = (double)B * l.L;
     prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
-    const int cib = l.taps == 15 ? 32 : 64;
-    const size_t smem = ((size_t)(2 * l.h3w_mrep * 16 + 2 * cib) * 144 + 16) * 2;
+    const int xg = l.taps == 15 ? 4 : 8;
+    const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * 132 + (size_t)2 * xg * 148 + 8) * 16;
     const dim3 grid(l.h3w_ksplit, l.h3w_nblocks, l.h3w_mblocks);
     const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, grid, smem, st);
     prof_end(st);
@@ -795,7 +800,10 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                          (i > 0 && l.h3d) ? reinterpret_cast<unsigned*>(ws + c->h3_slot) : (unsigned*)nullptr);
             WUNET_CHECK_LAUNCH();
             if (i > 0 && l.h3d) {      // power-of-two scale of g_z for the fp16-split GEMMs (kept per layer: the side stream reads it late)
-                WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(ws + c->h3_slot), ws + c->h3_slot + 8 + 4 * i);
+                float* sc = ws + c->h3_slot + 8 + 4 * i;
+                WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(ws + c->h3_slot), sc);
+                WUNET_CHECK_LAUNCH();
+                launch_split(ws + l.g, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl), sc, c->B, l.cout, l.L, st);
                 WUNET_CHECK_LAUNCH();
             }
         }
@@ -814,7 +822,10 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 WUNET_CHECK_LAUNCH();
             } else {
                 int rc;
-                if (l.h3w) rc = launch_wgrad_h3(l, xin, ws + l.g, ws + c->h3_slot + 8 + 4 * i, ws + c->wgpart_off, c->B, sd);
+                if (l.h3w)
+                    rc = launch_wgrad_h3(l, reinterpret_cast<const wunet_half*>(ws + l.xh), reinterpret_cast<const wunet_half*>(ws + l.xl),
+                                         reinterpret_cast<const wunet_half*>(ws + l.gzh), reinterpret_cast<const wunet_half*>(ws + l.gzl),
+                                         ws + c->h3_slot + 8 + 4 * i, ws + c->wgpart_off, c->B, sd);
                 else {
                     const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
                     rc = launch_wgrad_any(l.taps, w, l.w, sd);
@@ -832,10 +843,8 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         if (i > 0 && l.h3d) {
             // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
             float* sc = ws + c->h3_slot + 8 + 4 * i;
-            wunet_half* gh = reinterpret_cast<wunet_half*>(ws + c->h3_gz_hi);
-            wunet_half* gl = reinterpret_cast<wunet_half*>(ws + c->h3_gz_lo);
-            launch_split(ws + l.g, gh, gl, sc, c->B, l.cout, l.L, st);
-            WUNET_CHECK_LAUNCH();
+            wunet_half* gh = reinterpret_cast<wunet_half*>(ws + l.gzh);
+            wunet_half* gl = reinterpret_cast<wunet_half*>(ws + l.gzl);
             int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp / l.h3d_mrep, gh, gl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,

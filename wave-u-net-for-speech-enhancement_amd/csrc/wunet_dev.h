@@ -49,6 +49,20 @@ __device__ __forceinline__ wunet_f4 wunet_mfma16h(wunet_h8 a, wunet_h8 b, wunet_
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// Transposed LDS read (ds_read_b64_tr_b16), twice: within each 16-lane group the lanes' 8-byte pieces form a
+// [4 rows][16 columns] half matrix (row j = lanes 4j..4j+3, 4 columns each) and lane i receives column i.  Measured on
+// gfx950: out[lane i][j] = in[lane 4j + (i >> 2)].half[i & 3].  p0 feeds halfs 0-3 of the result, p1 halfs 4-7: an MFMA
+// operand whose 8 consecutive K live in 8 different rows of a K-major LDS image.
+__device__ __forceinline__ wunet_h8 wunet_ldtr8(const wunet_half* p0, const wunet_half* p1)
+{
+    typedef short wunet_s4 __attribute__((ext_vector_type(4)));
+    typedef short wunet_s8 __attribute__((ext_vector_type(8)));
+    const wunet_s4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wunet_s4 __attribute__((address_space(3)))*)p0);
+    const wunet_s4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wunet_s4 __attribute__((address_space(3)))*)p1);
+    const wunet_s8 r = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(wunet_h8, r);
+}
+
 // 8 halfs starting O halfs into the 24 halfs p[0] | p[1] | p[2] (O in 0..16, compile time): the tap shift of the
 // weight-gradient B operand, done with v_alignbit on aligned 16-byte LDS pieces
 typedef unsigned wunet_u4 __attribute__((ext_vector_type(4)));

@@ -29,7 +29,7 @@ struct ConvH3Args {
 };
 
 template <int TAPS, int M_REP>
-__global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
+__global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_kernel(ConvH3Args A)
 {
     constexpr int PAD = TAPS / 2;
     constexpr int TG = 5;                         // taps per stage
@@ -59,10 +59,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
         xc8[it] = f < XP ? ((r / COLS) | (f >= 4 * COLS ? 8 : 0)) : -1;       // bits 0-2: channel group in the chunk, bit 3: lo array
         xcol[it] = r % COLS;
     }
-    // B-fragment base (halfs): plane q, column of this lane
-    int boff[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) boff[nt] = (q * COLS + wave * 64 + nt * 16 + i16 + (8 - PAD)) * 8;
+    // The MFMA column j of n-tile nt is position wave*64 + 4*j + nt, so a lane ends up with 4 consecutive positions of a
+    // row (one 16-byte store, 256 contiguous bytes per row and wave).  For conflict-free fragment reads the x tile is
+    // kept de-interleaved in LDS: column c of a plane lives at piece (c & 3) * COLS/4 + (c >> 2).
+    const int boff = (q * COLS + wave * 16 + i16) * 8;
     const int aoff = (q * 16 + i16) * 8;
 
     wunet_f4 acc[M_REP][4];
@@ -105,7 +105,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
                 const int c8g = ch * 4 + (xc8[it] & 7);
                 const int l = l0 - 8 + xcol[it];
                 const bool ok = xc8[it] >= 0 && c8g < A.C8 && b < A.B && l >= 0 && l < L;
-                if (f < XP) wunet_sth8(xs + (size_t)f * 8, wunet_selh8(ok, xreg[it]));
+                const int pc = (f / COLS) * COLS + (xcol[it] & 3) * (COLS / 4) + (xcol[it] >> 2);
+                if (f < XP) wunet_sth8(xs + (size_t)pc * 8, wunet_selh8(ok, xreg[it]));
             }
         }
 #pragma unroll
@@ -126,8 +127,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                bh[nt] = wunet_ldh8(xs + boff[nt] + tap * 8);
-                bl[nt] = wunet_ldh8(xs + 4 * COLS * 8 + boff[nt] + tap * 8);
+                const int e = nt + tap + 8 - PAD;        // column = 4 * (wave*16 + i16) + e
+                bh[nt] = wunet_ldh8(xs + boff + ((e & 3) * (COLS / 4) + (e >> 2)) * 8);
+                bl[nt] = wunet_ldh8(xs + 4 * COLS * 8 + boff + ((e & 3) * (COLS / 4) + (e >> 2)) * 8);
             }
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt)
@@ -146,17 +148,20 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        const int l = l0 + wave * 64 + i16 * 4;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int l = l0 + wave * 64 + nt * 16 + i16;
+        for (int r = 0; r < 4; ++r) {
+            const int co = (mt0 + mt) * 16 + q * 4 + r;
+            const float bv = (A.bias && co < A.Cout) ? A.bias[co] : 0.0f;
+            wunet_f4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = (mt0 + mt) * 16 + q * 4 + r;
+            for (int nt = 0; nt < 4; ++nt) {
                 const float v = acc[mt][nt][r] * inv;
                 s1[r] += v;
                 s2[r] += v * v;
-                if (co < A.Cout && b < A.B) A.out[((size_t)b * A.Cout + co) * L + l] = v + (A.bias ? A.bias[co] : 0.0f);
+                o[nt] = v + bv;
             }
+            if (co < A.Cout && b < A.B) wunet_st4(A.out + ((size_t)b * A.Cout + co) * L + l, o);
         }
         if (A.stats) {
 #pragma unroll
@@ -179,51 +184,53 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_h3_kernel(ConvH3Args A)
 
 // ---------------------------------------------------------------------------- weight gradient
 // dW[co][ci][t] = sum_{b,p} g_z[b][co][p] * x[b][ci][p + t - PAD] as a GEMM over positions (K) on the fp16 split:
-// A = g_z (rows co, K = 8 consecutive positions per lane), B = x with one n-tile = 16 input channels at ONE tap, so the
-// tap shift is uniform per MFMA.  Both operands are staged from the fp32 activations ([B][C][L], positions
-// contiguous) and split into hi/lo on the way into LDS (ds_write_b64 of 4 halfs); fragments are aligned ds_read_b128
-// of a [row][144] half image (row stride = 2 sixteen-byte slots mod 16: conflict free), and the tap shift is a
-// compile-time funnel shift (v_alignbit) over three consecutive pieces held in registers.
+// A = g_z (rows co), B = x with one n-tile = 16 input channels at ONE tap, so the tap shift is uniform per MFMA.
+// Both operands come from the split layout [B][C8][L][8] (the one the conv kernels use) by straight 16-byte copies
+// into LDS images [hi|lo][channel group][position][8]; an MFMA operand (8 consecutive positions of one channel) is two
+// transposed reads (ds_read_b64_tr_b16) of that position-major image.  Plane strides are 4 mod 16 pieces: the 32 lanes
+// of a transposed read then cover all 64 banks.  The tap shift is a compile-time funnel shift (v_alignbit) over three
+// consecutive 8-position pieces held in registers, shared by the taps of a wave.
 //   TAPS = 15: block = M_REP*16 co x 32 ci; wave = (ci group, tap half of 8)  -> M_REP*8 accumulator tiles
 //   TAPS =  5: block = M_REP*16 co x 64 ci; wave = ci group, all 5 taps        -> M_REP*5 accumulator tiles
 // Split-K over gridDim.x like wgrad_mfma_kernel: partial dW [gridDim.x][Cout][Cin][TAPS], reduced by wgrad_reduce_kernel.
 struct WgradH3Args {
-    const float* x;      // [B][Cin][L]
-    const float* g;      // [B][Cout][L]  g_z
+    const wunet_half* xh; const wunet_half* xl;   // [B][XC8][L][8]
+    const wunet_half* gh; const wunet_half* gl;   // [B][GC8][L][8]  scaled g_z
     const float* sc;     // {scale, 1/scale} of g_z
     float* part;
-    int B, Cin, Cout, L, logL, chunks_per_split;
+    int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
 };
 
 template <int TAPS, int M_REP>
 __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
 {
-    constexpr int PAD = TAPS / 2;
-    constexpr int TP = 128, ROW = 144;
+    constexpr int TP = 128, GP = 132, XPOS = 148;   // positions per chunk; plane strides (pieces) of the g_z / x images
     constexpr int WG = TAPS == 15 ? 2 : 4;          // ci groups of 16 per block
     constexpr int TW = TAPS == 15 ? 8 : 5;          // taps per wave
-    constexpr int OB = TAPS == 15 ? 1 : 8 - PAD;    // funnel offset of the wave's first tap
-    constexpr int CIB = WG * 16, GROWS = M_REP * 16;
-    constexpr int GIT = GROWS * (TP / 4) / WUNET_THREADS;                      // 2 * M_REP float4 per thread
-    constexpr int XF4 = CIB * (ROW / 4);
-    constexpr int XIT = (XF4 + WUNET_THREADS - 1) / WUNET_THREADS;
+    constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;    // funnel offset of the wave's first tap
+    constexpr int CIB = WG * 16, XG = CIB / 8, GG = M_REP * 2;
+    constexpr int GPC = 2 * GG * TP;                // pieces staged per chunk: g_z, x
+    constexpr int XPC = 2 * XG * XPOS;
+    constexpr int GIT = GPC / WUNET_THREADS;        // 2 * M_REP
+    constexpr int XIT = (XPC + WUNET_THREADS - 1) / WUNET_THREADS;
     WUNET_DYN_SMEM(smem);
-    wunet_half* gh = reinterpret_cast<wunet_half*>(smem);                      // [GROWS][ROW]
-    wunet_half* gl = gh + GROWS * ROW;
-    wunet_half* xh = gl + GROWS * ROW;                                         // [CIB][ROW]
-    wunet_half* xl = xh + CIB * ROW;                                           // (+16 halfs of slack behind it)
+    wunet_half* gs = reinterpret_cast<wunet_half*>(smem);                      // [hi|lo][GG][GP][8]
+    wunet_half* xs = gs + 2 * GG * GP * 8;                                     // [hi|lo][XG][XPOS][8] (+ slack behind it)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
     const int grp = TAPS == 15 ? wave >> 1 : wave;
-    const int th = TAPS == 15 ? wave & 1 : 0;
-    const int t0 = th * 8;
-    const int co0 = blockIdx.z * GROWS, ci0 = blockIdx.y * CIB;
+    const int t0 = TAPS == 15 ? (wave & 1) * 8 : 0;
+    const int co0 = blockIdx.z * M_REP * 16, ci0 = blockIdx.y * CIB;
     const int L = A.L;
     const long long nchunks = ((long long)A.B * L) / TP;
     const long long kbeg = (long long)blockIdx.x * A.chunks_per_split;
     long long kend = kbeg + A.chunks_per_split;
     if (kend > nchunks) kend = nchunks;
-    const float s = A.sc[0];
+
+    // transposed-read bases (halfs): lane (j = i16>>2, cq = i16&3) feeds row j, channels 4cq..4cq+3 of its 16-lane group
+    const int tr_row = (i16 >> 2) + q * 8, tr_pl = (i16 & 3) >> 1, tr_h = (i16 & 1) * 4;
+    const int gbase = (tr_pl * GP + tr_row) * 8 + tr_h;
+    const int xbase = ((grp * 2 + tr_pl) * XPOS + tr_row + t0) * 8 + tr_h;
 
     wunet_f4 acc[M_REP][TW];
 #pragma unroll
@@ -231,23 +238,27 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) acc[mt][tw] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
-    wunet_f4 greg[GIT], xreg[XIT];
+    wunet_h8 greg[GIT], xreg[XIT];
 #define WUNET_WH3_PREFETCH(K_)                                                                                    \
     {                                                                                                             \
         const long long n0_ = (K_) * TP;                                                                          \
         const int b_ = (int)(n0_ >> A.logL), l0_ = (int)(n0_ & (L - 1));                                          \
         _Pragma("unroll") for (int it = 0; it < GIT; ++it) {                                                      \
             const int f_ = tid + it * WUNET_THREADS;                                                              \
-            const int co_ = co0 + (f_ >> 5);                                                                      \
-            const bool ok_ = co_ < A.Cout;                                                                        \
-            greg[it] = wunet_ld4(A.g + (ok_ ? ((size_t)b_ * A.Cout + co_) * L + l0_ + (f_ & 31) * 4 : 0));        \
+            const int pl_ = f_ / TP, pos_ = f_ - pl_ * TP;                 /* plane = which * GG + group */       \
+            const int c8_ = (co0 >> 3) + (pl_ % GG);                                                              \
+            const bool ok_ = c8_ < A.GC8;                                                                         \
+            const wunet_half* src_ = pl_ >= GG ? A.gl : A.gh;                                                     \
+            greg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)b_ * A.GC8 + c8_) * L + l0_ + pos_) * 8 : 0));          \
         }                                                                                                         \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
             const int f_ = tid + it * WUNET_THREADS;                                                              \
-            const int r_ = f_ / (ROW / 4), c4_ = f_ - r_ * (ROW / 4);                                             \
-            const int l_ = l0_ - 8 + c4_ * 4;                                                                     \
-            const bool ok_ = f_ < XF4 && ci0 + r_ < A.Cin && l_ >= 0 && l_ < L;                                   \
-            xreg[it] = wunet_ld4(A.x + (ok_ ? ((size_t)b_ * A.Cin + ci0 + r_) * L + l_ : 0));                     \
+            const int pl_ = f_ / XPOS, pos_ = f_ - pl_ * XPOS;                                                    \
+            const int c8_ = (ci0 >> 3) + (pl_ % XG);                                                              \
+            const int l_ = l0_ - 8 + pos_;                                                                        \
+            const bool ok_ = f_ < XPC && c8_ < A.XC8 && l_ >= 0 && l_ < L;                                        \
+            const wunet_half* src_ = pl_ >= XG ? A.xl : A.xh;                                                     \
+            xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)b_ * A.XC8 + c8_) * L + l_) * 8 : 0));                  \
         }                                                                                                         \
     }
     if (kbeg < kend) WUNET_WH3_PREFETCH(kbeg)
@@ -258,29 +269,17 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
 #pragma unroll
         for (int it = 0; it < GIT; ++it) {
             const int f = tid + it * WUNET_THREADS;
-            const bool ok = co0 + (f >> 5) < A.Cout;
-            const wunet_f4 v = wunet_sel4(ok, greg[it]);
-            wunet_half h[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wunet_split_h(v[e] * s, h[e], lo[e]);
-            const int o = (f >> 5) * ROW + (f & 31) * 4;
-            wunet_sth4(gh + o, h);
-            wunet_sth4(gl + o, lo);
+            const int pl = f / TP, pos = f - pl * TP;
+            const bool ok = (co0 >> 3) + (pl % GG) < A.GC8;
+            wunet_sth8(gs + ((size_t)pl * GP + pos) * 8, wunet_selh8(ok, greg[it]));
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int f = tid + it * WUNET_THREADS;
-            const int r = f / (ROW / 4), c4 = f - r * (ROW / 4);
-            const int l = l0 - 8 + c4 * 4;
-            const bool ok = ci0 + r < A.Cin && l >= 0 && l < L;
-            const wunet_f4 v = wunet_sel4(ok, xreg[it]);
-            wunet_half h[4], lo[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) wunet_split_h(v[e], h[e], lo[e]);
-            if (f < XF4) {
-                wunet_sth4(xh + r * ROW + c4 * 4, h);
-                wunet_sth4(xl + r * ROW + c4 * 4, lo);
-            }
+            const int pl = f / XPOS, pos = f - pl * XPOS;
+            const int l = l0 - 8 + pos;
+            const bool ok = (ci0 >> 3) + (pl % XG) < A.XC8 && l >= 0 && l < L;
+            if (f < XPC) wunet_sth8(xs + (size_t)f * 8, wunet_selh8(ok, xreg[it]));
         }
         __syncthreads();
         if (k + 1 < kend) WUNET_WH3_PREFETCH(k + 1)
@@ -289,14 +288,15 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
             wunet_h8 ah[M_REP], al[M_REP], ph[3], pl[3];
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt) {
-                ah[mt] = wunet_ldh8(gh + (mt * 16 + i16) * ROW + ks * 32 + q * 8);
-                al[mt] = wunet_ldh8(gl + (mt * 16 + i16) * ROW + ks * 32 + q * 8);
+                const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
+                ah[mt] = wunet_ldtr8(p, p + 32);
+                al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
             }
-            const int xb = (grp * 16 + i16) * ROW + ks * 32 + q * 8 + t0;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
-                ph[m] = wunet_ldh8(xh + xb + m * 8);
-                pl[m] = wunet_ldh8(xl + xb + m * 8);
+                const wunet_half* p = xs + xbase + (ks * 32 + m * 8) * 8;
+                ph[m] = wunet_ldtr8(p, p + 32);
+                pl[m] = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
             }
 #define WUNET_WH3_TAP(TW_)                                                                                         \
             if (TW_ < TW && t0 + TW_ < TAPS) {                                                                     \
