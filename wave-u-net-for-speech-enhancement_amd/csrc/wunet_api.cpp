@@ -272,6 +272,7 @@ struct LayerPlan {
     // fp16-split path (large levels only)
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
+    int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps;   // weight gradient uses wgrad_h3_kernel
     size_t xh, xl;                // split activated input (float offsets)
     size_t gzh, gzl;              // split scaled g_z (float offsets)
@@ -333,7 +334,14 @@ void layout_workspace(wunet_ctx* c)
         l.s = off; off += align64(l.cout);
         l.mean = off; off += align64(l.cout);
         l.rstd = off; off += align64(l.cout);
-        l.xin = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
+        {
+            const bool big = c->h3 && l.L >= 256 && l.f.nrep == 4 && l.f.ksplit == 1;
+            l.h3f = big ? 1 : 0;
+            l.h3d = (big && i > 0 && l.d.nrep == 4 && l.d.ksplit == 1) ? 1 : 0;
+            l.h3w = (l.h3d && l.cin >= 16 && !getenv("WUNET_NO_H3W")) ? 1 : 0;
+            l.h3x = (l.h3f && l.h3w && !getenv("WUNET_NO_H3X")) ? 1 : 0;
+        }
+        l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
     }
     c->stats_off = off; off += align64(stats_max);
     c->wpkf_off = off; off += align64(wpk);
@@ -342,9 +350,6 @@ void layout_workspace(wunet_ctx* c)
     size_t wfh = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
-        const bool big = c->h3 && l.L >= 256 && l.f.nrep == 4 && l.f.ksplit == 1;
-        l.h3f = big ? 1 : 0;
-        l.h3d = (big && i > 0 && l.d.nrep == 4 && l.d.ksplit == 1) ? 1 : 0;
         l.xh = l.xl = 0; l.h3f_wpk = l.h3d_wpk = 0;
         if (l.h3f) {
             const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
@@ -369,7 +374,6 @@ void layout_workspace(wunet_ctx* c)
         l.k3 = off; off += align64(l.cout);
         l.d_wpk = wpkb;
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
-        l.h3w = (l.h3d && l.cin >= 16 && !getenv("WUNET_NO_H3W")) ? 1 : 0;
         if (l.h3w) {
             const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
             l.h3w_mrep = pick_mrep_h3(mt);
@@ -605,7 +609,22 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             const size_t n4 = (size_t)c->B * l.cin * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
-            if (l.L < 4) {
+            if (l.h3x) {
+                PrepH3Args ph{};
+                ph.z0 = pa.z0; ph.a0 = pa.a0; ph.s0 = pa.s0;
+                ph.xh = reinterpret_cast<wunet_half*>(ws + l.xh); ph.xl = reinterpret_cast<wunet_half*>(ws + l.xl);
+                ph.B = c->B; ph.C0 = l.c0; ph.C1 = l.cin - l.c0; ph.C8 = (l.cin + 7) / 8; ph.L = l.L; ph.logL = l.logL;
+                ph.kind = l.kind == LK_UPCAT ? 1 : 0;
+                if (l.kind == LK_UPCAT) {
+                    const LayerPlan& k = c->ly[l.src1];
+                    ph.z1 = ws + k.z; ph.a1 = ws + k.a; ph.s1 = ws + k.s;
+                    ph.up_scale = (float)(l.L / 2 - 1) / (float)(l.L - 1);
+                }
+                const size_t nt = (size_t)c->B * ph.C8 * (l.L / 4);
+                size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (hb > 16384) hb = 16384;
+                WUNET_LAUNCH(prep_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, ph);
+            } else if (l.L < 4) {
                 if (l.kind == LK_UPCAT) {
                     const LayerPlan& k = c->ly[l.src1];
                     pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
@@ -632,8 +651,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
             wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);
             wunet_half* xl = reinterpret_cast<wunet_half*>(ws + l.xl);
-            launch_split(xin, xh, xl, nullptr, c->B, l.cin, l.L, st);
-            WUNET_CHECK_LAUNCH();
+            if (!l.h3x) {
+                launch_split(xin, xh, xl, nullptr, c->B, l.cin, l.L, st);
+                WUNET_CHECK_LAUNCH();
+            }
             int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp / l.h3f_mrep, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], nullptr,

@@ -83,6 +83,73 @@ __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x
     }
 }
 
+// ---------------------------------------------------------------------------- conv input, produced split
+// prep_decim_kernel / prep_upcat_kernel (wunet_elementwise.h) writing the activated conv input straight into the
+// hi / lo [B][C8][L][8] layout: the fp32 tensor and its split pass do not exist for these layers.  One thread per
+// (channel group, 4 samples).  kind 0: decimate (C1 = 0), 1: upsample x2 + skip concat.
+struct PrepH3Args {
+    const float* z0; const float* a0; const float* s0;
+    const float* z1; const float* a1; const float* s1;
+    wunet_half* xh; wunet_half* xl;
+    int B, C0, C1, C8, L, logL, kind;
+    float up_scale;
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
+{
+    const int l4n = A.L >> 2, Lh = A.L >> 1, C = A.C0 + A.C1;
+    const size_t total = (size_t)A.B * A.C8 * l4n;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const int l4 = (int)(i & (size_t)(l4n - 1));
+        const size_t row = i >> (A.logL - 2);
+        const int b = (int)(row / (size_t)A.C8), c8 = (int)(row - (size_t)b * A.C8);
+        float v[8][4];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            if (c >= C) {
+                v[e][0] = v[e][1] = v[e][2] = v[e][3] = 0.0f;
+            } else if (A.kind == 0) {
+                const float a = A.a0[c], s = A.s0[c];
+                const float* src = A.z0 + ((size_t)b * A.C0 + c) * (size_t)(2 * A.L) + 8 * l4;
+                const wunet_f4 u = wunet_ld4(src), w = wunet_ld4(src + 4);
+                v[e][0] = wunet_lrelu(a * u[0] + s); v[e][1] = wunet_lrelu(a * u[2] + s);
+                v[e][2] = wunet_lrelu(a * w[0] + s); v[e][3] = wunet_lrelu(a * w[2] + s);
+            } else if (c < A.C0) {
+                const float a = A.a0[c], s = A.s0[c];
+                const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int i0, i1; float l0, l1;
+                    wunet_up_coord(4 * l4 + j, Lh, A.up_scale, i0, i1, l0, l1);
+                    v[e][j] = l0 * wunet_lrelu(a * zr[i0] + s) + l1 * wunet_lrelu(a * zr[i1] + s);
+                }
+            } else {
+                const int cs = c - A.C0;
+                const float a = A.a1[cs], s = A.s1[cs];
+                const wunet_f4 u = wunet_ld4(A.z1 + ((size_t)b * A.C1 + cs) * A.L + 4 * l4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[e][j] = wunet_lrelu(a * u[j] + s);
+            }
+        }
+        wunet_half* ph = A.xh + (row * A.L + 4 * (size_t)l4) * 8;
+        wunet_half* pl = A.xl + (row * A.L + 4 * (size_t)l4) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wunet_h8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wunet_half a, d;
+                wunet_split_h(v[e][j], a, d);
+                wunet_put_half(h, e, a);
+                wunet_put_half(l, e, d);
+            }
+            wunet_sth8(ph + 8 * j, h);
+            wunet_sth8(pl + 8 * j, l);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- weight pack
 // dst[mt][chunk][tap][q][i][e] = W(row = mt*16+i, k-channel = chunk*32+q*8+e, tap); forward: W = w[row][kch][tap];
 // data gradient (transposed): W = w[kch][row][TAPS-1-tap].  hi and lo arrays.
