@@ -285,6 +285,7 @@ struct wunet_ctx {
     int n, ci, B, T, NL;
     std::vector<LayerPlan> ly;
     size_t stats_off, wpkf_off, spart_off, fwd_floats;
+    size_t bmax_off, bound_off;   // pass A maxima / per-channel |g_z| bounds (fp16-split scale)
     size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
     int head_blocks;
     int h3 = 0;                   // fp16-split GEMMs enabled for the large levels
@@ -337,9 +338,10 @@ void layout_workspace(wunet_ctx* c)
         {
             const bool big = c->h3 && l.L >= 256 && l.f.nrep == 4 && l.f.ksplit == 1;
             l.h3f = big ? 1 : 0;
-            l.h3d = (big && i > 0 && l.d.nrep == 4 && l.d.ksplit == 1) ? 1 : 0;
-            l.h3w = (l.h3d && l.cin >= 16 && !getenv("WUNET_NO_H3W")) ? 1 : 0;
-            l.h3x = (l.h3f && l.h3w && !getenv("WUNET_NO_H3X")) ? 1 : 0;
+            // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
+            l.h3d = (big && i > 0 && l.d.nrep == 4 && l.d.ksplit == 1 && l.cin >= 16) ? 1 : 0;
+            l.h3w = l.h3d;
+            l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
         }
         l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
     }
@@ -395,6 +397,8 @@ void layout_workspace(wunet_ctx* c)
         if ((size_t)l.a_split * l.cout * 2 > bpart_max) bpart_max = (size_t)l.a_split * l.cout * 2;
     }
     c->bpart_off = off; off += align64(bpart_max);
+    c->bmax_off = off; off += align64(bpart_max);
+    c->bound_off = off; off += align64(4096);
     c->wgpart_off = off; off += align64(wgpart_max);
     c->wpkb_off = off; off += align64(wpkb);
     c->gh_off = off; off += align64((size_t)B * T);
@@ -418,7 +422,7 @@ void layout_workspace(wunet_ctx* c)
     c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
     c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
     (void)gzs;
-    c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // amax word, then {scale, 1/scale} per layer
+    c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // {scale, 1/scale} of g_z per layer (offset 8 + 4*layer)
     c->total_floats = off;
 }
 
@@ -757,7 +761,6 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 WUNET_LAUNCH(pack_h3_kernel, dim3(128, n3), dim3(WUNET_THREADS), 0, st, t3);
                 WUNET_CHECK_LAUNCH();
             }
-            hipMemsetAsync(ws + c->h3_slot, 0, 8 * sizeof(float), st);      // amax word of the gradient scale
         }
         // head backward: gh = gout * tanh', d wh, d bh
         const LayerPlan& l = c->ly[NL - 1];
@@ -777,7 +780,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         // ---- pass A: assemble dL/d(BN output), LeakyReLU', BN-backward partial sums
         PassAArgs p{};
         p.z = ws + l.z; p.a = ws + l.a; p.s = ws + l.s; p.mean = ws + l.mean; p.rstd = ws + l.rstd;
-        p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL;
+        p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL;
         const dim3 ga(l.cout, l.a_split);
         const bool tiny = l.L < 4;
         if (i == NL - 1) {
@@ -802,31 +805,32 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         b.part = ws + c->bpart_off; b.rows = l.a_split; b.gamma = params[4 * i + 2]; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
         b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
         b.C = l.cout; b.count = (double)c->B * l.L;
+        b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
         WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         WUNET_CHECK_LAUNCH();
 
-        // ---- g_z = k1*g + k2*z + k3, materialised once for both gradient GEMMs
+        // ---- g_z = k1*g + k2*z + k3, materialised once for both gradient GEMMs (fp32 in place, or scaled hi/lo halves)
         {
             const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
-            if (i > 0 && l.h3d && blocks > 512) blocks = 512;     // one atomicMax per block on ONE word: keep them few
-            if (tiny)
+            if (i > 0 && l.h3d) {
+                const int c8 = (l.cout + 7) / 8;
+                const size_t nt = (size_t)c->B * c8 * (l.L / 4);
+                size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (hb > 8192) hb = 8192;
+                WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                             (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
+                             ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
+                             c->B, l.cout, c8, l.L, l.logL);
+            } else if (tiny)
                 WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
                              (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
                              (size_t)c->B * l.cout * l.L, ws + l.g);
             else
-            WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                         (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g,   // in place
-                         (i > 0 && l.h3d) ? reinterpret_cast<unsigned*>(ws + c->h3_slot) : (unsigned*)nullptr);
+                WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                             (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
             WUNET_CHECK_LAUNCH();
-            if (i > 0 && l.h3d) {      // power-of-two scale of g_z for the fp16-split GEMMs (kept per layer: the side stream reads it late)
-                float* sc = ws + c->h3_slot + 8 + 4 * i;
-                WUNET_LAUNCH(scale_from_amax_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(ws + c->h3_slot), sc);
-                WUNET_CHECK_LAUNCH();
-                launch_split(ws + l.g, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl), sc, c->B, l.cout, l.L, st);
-                WUNET_CHECK_LAUNCH();
-            }
         }
         // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
         //      + deterministic reduce

@@ -61,6 +61,26 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* red)
     b = red[WUNET_THREADS];
 }
 
+// max of two non-negative floats over the block (same LDS buffer, after a block_sum2); result valid in thread 0
+__device__ __forceinline__ void block_max2(float& a, float& b, double* red)
+{
+    float* fr = reinterpret_cast<float*>(red);
+    const int tid = threadIdx.x;
+    __syncthreads();
+    fr[tid] = a;
+    fr[WUNET_THREADS + tid] = b;
+    __syncthreads();
+    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            fr[tid] = fmaxf(fr[tid], fr[tid + s]);
+            fr[WUNET_THREADS + tid] = fmaxf(fr[WUNET_THREADS + tid], fr[WUNET_THREADS + tid + s]);
+        }
+        __syncthreads();
+    }
+    a = fr[0];
+    b = fr[WUNET_THREADS];
+}
+
 // ---------------------------------------------------------------------------- BN forward finalize
 // grid = C.  Training: reduce the conv epilogue partials (bias-free sums) -> batch mean / biased var,
 // scale/shift for the consumers, saved mean/rstd for backward, running-stat update (unbiased var,
@@ -283,6 +303,7 @@ struct PassAArgs {
     const float* rstd;
     float* gpre;         // out [B][C][L]
     float* part;         // [nsplit][C][2]
+    float* pmax;         // nullptr or [nsplit][C][2]: max |g_pre|, max |z - mean| (bound of |g_z| for the fp16-split scale)
     const float* g0;     // HEAD: gh [B][L];  UP: dX [B][Cg0][2L];  ENC: dXdec [B][Cg0][L]
     const float* g1;     // HEAD: wh;         ENC: dXenc [B][C][L/2]
     int Cg0;             // channel count of the g0 tensor
@@ -303,6 +324,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     const float a = A.a[c], s = A.s[c], mu = A.mean[c], rstd = A.rstd[c];
     const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
     double s1 = 0.0, s2 = 0.0;
+    float mg = 0.0f, mz = 0.0f;
     for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += WUNET_THREADS) {
         const size_t p = q4 << 2;
         const int b = (int)(p >> A.logL), l = (int)(p & (size_t)(A.L - 1));
@@ -357,6 +379,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             go[j] = gv;
             s1 += (double)gv;
             s2 += (double)(gv * ((z[j] - mu) * rstd));
+            mg = fmaxf(mg, fabsf(gv));
+            mz = fmaxf(mz, fabsf(z[j] - mu));
         }
         wunet_st4(A.gpre + zi, go);
     }
@@ -365,6 +389,14 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         float* pr = A.part + ((size_t)blockIdx.y * A.C + c) * 2;
         pr[0] = (float)s1;
         pr[1] = (float)s2;
+    }
+    if (A.pmax) {
+        block_max2(mg, mz, red);
+        if (threadIdx.x == 0) {
+            float* pm = A.pmax + ((size_t)blockIdx.y * A.C + c) * 2;
+            pm[0] = mg;
+            pm[1] = mz;
+        }
     }
 }
 
@@ -378,6 +410,8 @@ struct BnBwdArgs {
     float* dbias;        // conv bias feeding training-mode BN: exact zero gradient
     float* k1; float* k2; float* k3;
     int C; double count;
+    const float* pmax;   // nullptr or pass A's [rows][C][2] maxima
+    float* bound;        // [C]: |k1| max|g| + |a m2 rstd| max|z - mean| + |a m1|  >=  max |g_z| of the channel
 };
 
 __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArgs A)
@@ -400,6 +434,20 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArg
         A.k1[c] = (float)a;
         A.k2[c] = (float)(-a * m2 * (double)A.rstd[c]);
         A.k3[c] = (float)(a * m2 * (double)A.rstd[c] * (double)A.mean[c] - a * m1);
+    }
+    if (A.pmax) {
+        float mg = 0.0f, mz = 0.0f;
+        for (int r = tid; r < A.rows; r += WUNET_THREADS) {
+            const float* pm = A.pmax + ((size_t)r * A.C + c) * 2;
+            mg = fmaxf(mg, pm[0]);
+            mz = fmaxf(mz, pm[1]);
+        }
+        block_max2(mg, mz, red);
+        if (tid == 0) {
+            const double m1 = s1 / A.count, m2 = s2 / A.count;
+            const double a = (double)A.gamma[c] * (double)A.rstd[c];
+            A.bound[c] = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)A.rstd[c]) * (double)mz + fabs(a * m1));
+        }
     }
 }
 
@@ -504,11 +552,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, i
 // g_z = k1*g + k2*z + k3 (BatchNorm backward folded to three per-channel coefficients), materialised once
 // per layer for its data-gradient and weight-gradient GEMMs
 __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
-                                                                        const float* k3, int C, int logL, size_t n4, float* gz, unsigned* amax)
+                                                                        const float* k3, int C, int logL, size_t n4, float* gz)
 {
-    // amax != nullptr: also track max |g_z| (float bits, atomicMax) - the power-of-two scale of the fp16-split path
-    __shared__ unsigned red[WUNET_THREADS];
-    unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int c = (int)((i >> (logL - 2)) % (size_t)C);
         const float a = k1[c], b = k2[c], d = k3[c];
@@ -517,20 +562,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const flo
         o.x = a * gv.x + b * zv.x + d; o.y = a * gv.y + b * zv.y + d;
         o.z = a * gv.z + b * zv.z + d; o.w = a * gv.w + b * zv.w + d;
         reinterpret_cast<float4*>(gz)[i] = o;
-        if (amax) {
-            const float mx = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
-            const unsigned u = wunet_fbits(mx);
-            m = u > m ? u : m;
-        }
-    }
-    if (amax) {
-        red[threadIdx.x] = m;
-        __syncthreads();
-        for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) atomicMax(amax, red[0]);
     }
 }
 

@@ -4,48 +4,6 @@
 #include "wunet_elementwise.h"
 #include "wunet_h3.h"
 
-// ---------------------------------------------------------------------------- scale of a gradient tensor
-// amax word holds max |x| as float bits (atomicMax on the unsigned pattern); sc[0] = 2^k with 2^k*amax in [512, 1024),
-// sc[1] = 2^-k.  An all-zero tensor gets 1.
-__global__ __launch_bounds__(WUNET_THREADS) void absmax_kernel(const float* x, size_t n4, unsigned* amax)
-{
-    __shared__ unsigned red[WUNET_THREADS];
-    unsigned m = 0;
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
-        const wunet_f4 v = wunet_ld4(x + 4 * i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned u = wunet_fbits(fabsf(v[j]));
-            m = u > m ? u : m;
-        }
-    }
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) atomicMax(amax, red[0]);
-}
-
-__global__ void scale_from_amax_kernel(unsigned* amax, float* sc)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        const unsigned u = *amax;
-        const int e = (int)((u >> 23) & 0xffu) - 127;                  // floor(log2(amax))
-        float s = 1.0f, inv = 1.0f;
-        if (u != 0 && u < 0x7f800000u) {
-            int k = 9 - e;                                             // 2^k * amax in [2^9, 2^10)
-            k = k > 100 ? 100 : (k < -100 ? -100 : k);
-            s = ldexpf(1.0f, k);
-            inv = ldexpf(1.0f, -k);
-        }
-        sc[0] = s;
-        sc[1] = inv;
-        *amax = 0;                                                     // ready for the next use
-    }
-}
-
 // fp32 [B][C][L]  ->  hi / lo [B][C8][L][8] halfs of sc[0]*x (sc == nullptr: unscaled).  One thread per
 // (channel group, 4 samples): 8 float4 loads, 4+4 16-byte stores.
 __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x, wunet_half* hi, wunet_half* lo, const float* sc,
@@ -76,6 +34,70 @@ __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x
                 wunet_split_h(s * v[e][j], a, d);
                 wunet_put_half(h, e, a);
                 wunet_put_half(l, e, d);
+            }
+            wunet_sth8(ph + 8 * j, h);
+            wunet_sth8(pl + 8 * j, l);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------- g_z, produced split
+// g_z = k1*g + k2*z + k3 (gz_materialize_kernel) written straight into the scaled hi / lo [B][C8][L][8] layout.  The
+// power-of-two scale comes from an upper bound of max |g_z| (bn_finalize_bwd_kernel's bound[c], max over channels) so
+// no pass over g_z is needed before writing it: 2^k * bound in [512, 1024).  Every block derives the same scale;
+// block 0 publishes {scale, 1/scale} for the GEMMs.  One thread per (channel group, 4 samples).
+__global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float* g, const float* z, const float* k1, const float* k2,
+                                                                     const float* k3, const float* bound, float* sc, wunet_half* hi,
+                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL)
+{
+    __shared__ float red[WUNET_THREADS];
+    float m = 0.0f;
+    for (int c = threadIdx.x; c < C; c += WUNET_THREADS) m = fmaxf(m, bound[c]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    float s = 1.0f, inv = 1.0f;
+    {
+        const unsigned u = wunet_fbits(red[0]);
+        if (u != 0 && u < 0x7f800000u) {
+            int k = 9 - ((int)((u >> 23) & 0xffu) - 127);
+            k = k > 100 ? 100 : (k < -100 ? -100 : k);
+            s = ldexpf(1.0f, k);
+            inv = ldexpf(1.0f, -k);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = s; sc[1] = inv; }
+    const int l4n = L >> 2;
+    const size_t total = (size_t)B * C8 * l4n;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const int l4 = (int)(i & (size_t)(l4n - 1));
+        const size_t row = i >> (logL - 2);
+        const int b = (int)(row / (size_t)C8), c8 = (int)(row - (size_t)b * C8);
+        wunet_f4 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            const bool ok = c < C;
+            const size_t o = ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4;
+            const wunet_f4 gv = wunet_ld4(g + o), zv = wunet_ld4(z + o);
+            const float a = k1[ok ? c : 0], bb = k2[ok ? c : 0], d = k3[ok ? c : 0];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[e][j] = ok ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;
+        }
+        wunet_half* ph = hi + (row * L + 4 * (size_t)l4) * 8;
+        wunet_half* pl = lo + (row * L + 4 * (size_t)l4) * 8;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wunet_h8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                wunet_half x, y;
+                wunet_split_h(v[e][j], x, y);
+                wunet_put_half(h, e, x);
+                wunet_put_half(l, e, y);
             }
             wunet_sth8(ph + 8 * j, h);
             wunet_sth8(pl + 8 * j, l);
