@@ -299,11 +299,11 @@ struct wunet_ctx {
 
 namespace {
 
-int pick_mrep_h3(int mtiles)
+int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
 {
     int best = 2, best_pad = 1 << 30;
-    const char* ord = getenv("WUNET_H3_ORDER");       // A/B switch for measurements
-    if (!ord) ord = "23";                             // ties go to the smaller tile: two blocks per CU hide the staging latency
+    const char* ord = getenv(env);                    // A/B switch for measurements
+    if (!ord) ord = dflt;
     for (const char* p = ord; *p; ++p) {
         const int m = *p - '0';
         const int pad = round_up(mtiles, m) - mtiles;
@@ -355,7 +355,7 @@ void layout_workspace(wunet_ctx* c)
         l.xh = l.xl = 0; l.h3f_wpk = l.h3d_wpk = 0;
         if (l.h3f) {
             const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
-            l.h3f_mrep = pick_mrep_h3(mt); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
+            l.h3f_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
             l.xh = off; off += align64((size_t)B * c8 * l.L * 4);
             l.xl = off; off += align64((size_t)B * c8 * l.L * 4);
             l.h3f_wpk = wfh; wfh += (size_t)l.h3f_mtp * l.h3f_nch * l.taps * 512;
@@ -378,8 +378,7 @@ void layout_workspace(wunet_ctx* c)
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
         if (l.h3w) {
             const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
-            l.h3w_mrep = pick_mrep_h3(mt);
-            if (l.h3w_mrep == 4 && round_up(mt, 3) == round_up(mt, 4)) l.h3w_mrep = 3;       // same padding: fewer registers
+            l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "432");
             l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
             l.h3w_nblocks = (l.cin + cib - 1) / cib;
             const long long chunks = (long long)B * l.L / 128;
@@ -413,7 +412,7 @@ void layout_workspace(wunet_ctx* c)
         LayerPlan& l = c->ly[i];
         if (!l.h3d) continue;
         const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
-        l.h3d_mrep = pick_mrep_h3(mt); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
+        l.h3d_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
         l.h3d_wpk = wbh; wbh += (size_t)l.h3d_mtp * l.h3d_nch * l.taps * 512;
         l.gzh = off; off += align64((size_t)B * c8 * l.L * 4);      // per layer: the side stream reads it late
         l.gzl = off; off += align64((size_t)B * c8 * l.L * 4);
@@ -448,7 +447,8 @@ int launch_conv_h3(int taps, int mrep, int mblocks, const wunet_half* xh, const 
     const double posn = (double)B * L;
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
     const size_t smem = (size_t)(2 * 4 * 272 + 2 * mrep * 5 * 64) * 16;
-    const dim3 grid((unsigned)((posn + 255) / 256), mblocks);
+    a.ntiles = (int)((posn + 255) / 256); a.mblocks = mblocks;
+    const dim3 grid((unsigned)(a.ntiles * mblocks));
     const int rc = wunet_launch_conv_h3(a, taps, mrep, grid, smem, st);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d (rc %d)", taps, mrep, rc);

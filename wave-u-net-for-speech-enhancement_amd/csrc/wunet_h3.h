@@ -26,6 +26,7 @@ struct ConvH3Args {
     float* out;                                   // [B][Cout][L] fp32
     float* stats;                                 // nullptr or [Cout][gridDim.x*4][2]
     int B, Cout, C8, NCH, L, logL;
+    int ntiles, mblocks;                          // 1-D grid of ntiles * mblocks blocks
 };
 
 template <int TAPS, int M_REP>
@@ -45,9 +46,20 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
     wunet_half* ws = xs + XP * 8;                                      // [hi|lo][M_REP][TG][4][16][8]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
-    const int n0 = blockIdx.x * 256;
+    // block -> (position tile, row block).  The row blocks of one position tile share its x tile: they get consecutive
+    // slots on ONE XCD (workgroup ids go round-robin over the 8 XCDs), so the tile is fetched into one L2 once.
+    int tile, mblk;
+    if ((A.ntiles & 7) == 0) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        mblk = k % A.mblocks;
+        tile = (k / A.mblocks) * 8 + xcd;
+    } else {
+        mblk = blockIdx.x % A.mblocks;
+        tile = blockIdx.x / A.mblocks;
+    }
+    const int n0 = tile * 256;
     const int b = n0 >> A.logL, l0 = n0 & (A.L - 1);
-    const int mt0 = blockIdx.y * M_REP;
+    const int mt0 = mblk * M_REP;
     const int L = A.L;
 
     // x slots: piece f -> (which, c8 local, column)
@@ -116,28 +128,31 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
         }
         __syncthreads();
         if (st + 1 < nstage) WUNET_H3_PREFETCH(st + 1)
+        // B fragments slide: with the interleaved column mapping, fragment (n-tile nt, tap) is column 4*lane + nt + tap,
+        // i.e. F[nt + tap] - each tap needs ONE new fragment pair, not four.
+        wunet_h8 fh[TG + 3], fl[TG + 3];
+#pragma unroll
+        for (int e = 0; e < TG + 3; ++e) {
+            const int ec = tg * TG + e + 8 - PAD;                 // column = 4 * (wave*16 + i16) + ec
+            const int po = ((ec & 3) * (COLS / 4) + (ec >> 2)) * 8;
+            fh[e] = wunet_ldh8(xs + boff + po);
+            fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
+        }
 #pragma unroll
         for (int tl = 0; tl < TG; ++tl) {
-            const int tap = tg * TG + tl;
-            wunet_h8 ah[M_REP], al[M_REP], bh[4], bl[4];
+            wunet_h8 ah[M_REP], al[M_REP];
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt) {
                 ah[mt] = wunet_ldh8(ws + ((mt * TG + tl) * 64) * 8 + aoff);
                 al[mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + tl) * 64 * 8 + aoff);
             }
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int e = nt + tap + 8 - PAD;        // column = 4 * (wave*16 + i16) + e
-                bh[nt] = wunet_ldh8(xs + boff + ((e & 3) * (COLS / 4) + (e >> 2)) * 8);
-                bl[nt] = wunet_ldh8(xs + 4 * COLS * 8 + boff + ((e & 3) * (COLS / 4) + (e >> 2)) * 8);
-            }
-#pragma unroll
             for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    acc[mt][nt] = wunet_mfma16h(al[mt], bh[nt], acc[mt][nt]);
-                    acc[mt][nt] = wunet_mfma16h(ah[mt], bl[nt], acc[mt][nt]);
-                    acc[mt][nt] = wunet_mfma16h(ah[mt], bh[nt], acc[mt][nt]);
+                    acc[mt][nt] = wunet_mfma16h(al[mt], fh[tl + nt], acc[mt][nt]);
+                    acc[mt][nt] = wunet_mfma16h(ah[mt], fl[tl + nt], acc[mt][nt]);
+                    acc[mt][nt] = wunet_mfma16h(ah[mt], fh[tl + nt], acc[mt][nt]);
                 }
         }
     }
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
                 }
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
                 if (i16 == 0 && co < A.Cout) {
-                    float* stp = A.stats + ((size_t)co * (gridDim.x * WUNET_WAVES) + (blockIdx.x * WUNET_WAVES + wave)) * 2;
+                    float* stp = A.stats + ((size_t)co * (A.ntiles * WUNET_WAVES) + (tile * WUNET_WAVES + wave)) * 2;
                     stp[0] = s1[r];
                     stp[1] = s2[r];
                 }
