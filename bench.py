@@ -31,6 +31,10 @@ FWD_FLOP_PER_FRAME = 4.885e9
 FWDBWD_FLOP_PER_FRAME = 14.643e9
 FWDBWD_BYTES_PER_FRAME = 99.54e6
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak == fp32 vector peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak (v_mfma_f32_16x16x32_f16)
+# the fp16-split kernels spend THREE f16 MFMA passes per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so their
+# ceiling in algorithmic (fp32) flops is a third of the f16 peak
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
 
 
@@ -109,10 +113,16 @@ def main():
                     help="train = the headline metric (BASELINE configs[2]/[3]); forward = eval-mode forward only "
                          "(configs[1], the enhancement.py path) - an extra measurement, same JSON shape")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam (f1)")
+    ap.add_argument("--gemm", choices=["split", "fp32"], default=None,
+                    help="GEMM arithmetic of the levels >= 256 samples: split = 3 x f16 MFMA on hi/lo fp16 halves of every fp32 "
+                         "operand, fp32 accumulation (default, == WUNET_H3=1); fp32 = v_mfma_f32_16x16x4_f32 everywhere (WUNET_H3=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if args.gemm is not None:
+        os.environ["WUNET_H3"] = "1" if args.gemm == "split" else "0"
+    split_gemm = os.environ.get("WUNET_H3", "1") != "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -213,8 +223,12 @@ def main():
                     traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
             except (OSError, ValueError, KeyError):
                 pass
-            roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+            is_split = "_h3_" in top["kernel"]
+            peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
+            roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": peak,
+                        "peak_note": ("2500 TFLOP/s dense f16 MFMA / 3 passes per fp32-equivalent product" if is_split
+                                      else "fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
+                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                         "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                         "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
@@ -239,7 +253,9 @@ def main():
                       if default_net else f"{args.frame}-sample frames/sec, {args.layers}-level Wave-U-Net, mode={args.mode} (extra)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": ("f32 (levels >= 256 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
+                      else "f32"),
+            "data": "synthetic",
             "config": {"workload": f"unet_basic {args.layers}-level, {args.frame}-sample frames, batch={args.batch} per GPU, fp32, "
                                    "training-mode forward + smooth_l1 + backward + " + ("torch.optim.Adam" if args.torch_adam else "fused HIP Adam") + " step "
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",
@@ -247,6 +263,7 @@ def main():
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
             "whole_step_tflops_per_gpu": per_gpu_fps * step_flop / 1e12,
             "whole_step_frac_of_fp32_peak": per_gpu_fps * step_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "gemm": "split" if split_gemm else "fp32",
             "whole_step_algorithmic_hbm_frac": per_gpu_fps * step_bytes / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,
             "roofline": roofline, "cpu_baseline": cpu,

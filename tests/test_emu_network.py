@@ -58,6 +58,55 @@ def test_train_step_matches_oracle(emu_engine, n, ci, B, T, loss):
         assert np.abs(post[k].numpy().astype(np.float64) - sd[k]).max() < 1e-5, k
 
 
+@pytest.fixture(scope="module")
+def emu_engine_h3():
+    """fp16-split GEMMs forced onto every level the kernels can run (wunet_set_h3(ctx, 2)): conv_h3 / wgrad_h3 /
+    prep_h3 / gz_split_h3, with the emulator's v_mfma_f32_16x16x32_f16, ds_read_b64_tr_b16 and v_alignbit models."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    return eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
+
+
+@pytest.mark.parametrize("n,ci,B,T,loss", [(2, 24, 1, 1024, "smooth_l1"),     # every level on the split path (L = 1024, 512, 256)
+                                            (3, 16, 2, 1024, "mse"),           # levels of 128 samples stay on the fp32 kernels
+                                            (1, 20, 3, 512, "l1")])            # channel counts that are not multiples of 8
+def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
+    """Same comparison as test_train_step_matches_oracle with the fp16-split path forced on: output within 2e-5, every
+    gradient within 3e-4 of its tensor's largest entry (the f32-vs-f64 noise floor of these nets is 1.5e-4)."""
+    eng = emu_engine_h3
+    m, sd, pkg_loss = _build(n, ci, eng)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step(sd, noisy, clean, n, ci, True, loss, precision="f64")
+    crit = {"mse": pkg_loss.mse_loss, "l1": pkg_loss.l1_loss, "smooth_l1": pkg_loss.smooth_l1_loss}[loss]()
+    crit._engine_override = eng
+    m.train()
+    out = m(torch.from_numpy(noisy))
+    lv = crit(torch.from_numpy(clean), out)
+    lv.backward()
+    # the split path must really have been planned: it needs extra workspace
+    import ctypes
+    sizes = []
+    for mode in (0, 2):
+        h = ctypes.c_void_p()
+        assert eng.lib.wunet_create(n, ci, B, T, ctypes.byref(h)) == 0
+        assert eng.lib.wunet_set_h3(h, mode) == 0
+        sizes.append(eng.lib.wunet_workspace_bytes(h, 0))
+        eng.lib.wunet_destroy(h)
+    assert sizes[1] != sizes[0]
+    assert np.abs(out.detach().numpy() - ref["out"]).max() < 2e-5
+    assert abs(lv.item() - ref["loss"]) < 1e-5
+    for k, p in m.named_parameters():
+        g, r = p.grad.numpy(), ref["grads"][k]
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            assert np.all(g == 0.0), k
+            continue
+        scale = max(np.abs(r).max(), 1e-6)
+        assert np.abs(g - r).max() < 3e-4 * scale + 1e-6, (k, np.abs(g - r).max(), scale)
+    post = m.state_dict()
+    for k in plan.buffer_names(n, ci):
+        assert np.abs(post[k].numpy().astype(np.float64) - sd[k]).max() < 1e-5, k
+
+
 def test_eval_forward_matches_oracle(emu_engine):
     n, ci, B, T = 3, 4, 2, 64
     m, sd, _ = _build(n, ci, emu_engine)

@@ -338,19 +338,33 @@ def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
         assert err < max(tol_g, 2e-3 * np.abs(r).max()) and rel < 2e-2, (k, err, rel)
 
 
-def test_fp16_split_path_matches_reference(pkg, dev):
-    """The opt-in fp16-split ("h3") GEMMs of the large levels (3 passes of v_mfma_f32_16x16x32_f16 on hi/lo halves,
-    power-of-two scaled gradients): same 1e-4 bar against the reference's ATen CPU path as the fp32 kernels, at a batch
-    large enough (16 x 16384) for the planner to route the big layers through them."""
+@pytest.mark.parametrize("mode,n,ci,B,T", [(1, 12, 24, 16, 16384),     # default planner: the levels >= 256 samples on the fp16-split kernels
+                                            (0, 12, 24, 16, 16384),     # WUNET_H3=0: the same net on the fp32 MFMA kernels only
+                                            (2, 3, 20, 3, 2048),        # forced split path on a small odd shape (ragged channel groups)
+                                            (2, 2, 24, 2, 1024)])
+def test_gemm_paths_match_reference(pkg, dev, mode, n, ci, B, T):
+    """Both GEMM arithmetics against the reference's ATen CPU path at the same 1e-4 bar: the fp16-split kernels
+    (3 passes of v_mfma_f32_16x16x32_f16 on hi/lo halves, power-of-two scaled gradients, conv_h3 / wgrad_h3 / prep_h3 /
+    gz_split_h3) and the fp32 kernels (v_mfma_f32_16x16x4_f32)."""
     eng_mod = importlib.import_module(PKG_NAME + ".engine")
-    n, ci, B, T = 12, 24, 16, 16384
     noisy, clean = plan.golden_batch(B, T, 5)
     sd = plan.golden_state(n, ci, 0)
     m = pkg.Model(n_layers=n, channels_interval=ci)
     m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
     m.to(dev).train()
-    m._engine_override = eng_mod.Engine(h3=True)
+    eng = eng_mod.Engine(h3=mode)
+    m._engine_override = eng
+    if mode:                                  # the split path must really be planned: it changes the workspace
+        sizes = []
+        for md in (0, mode):
+            h = ctypes.c_void_p()
+            assert eng.lib.wunet_create(n, ci, B, T, ctypes.byref(h)) == 0
+            assert eng.lib.wunet_set_h3(h, md) == 0
+            sizes.append(eng.lib.wunet_workspace_bytes(h, 0))
+            eng.lib.wunet_destroy(h)
+        assert sizes[0] != sizes[1]
     crit = pkg.smooth_l1_loss()
+    crit._engine_override = eng
     out = m(_t(noisy, dev))
     lv = crit(_t(clean, dev), out)
     lv.backward()
@@ -361,10 +375,13 @@ def test_fp16_split_path_matches_reference(pkg, dev):
     l2.backward()
     assert (out.detach().cpu() - o2.detach()).abs().max().item() < TOL
     assert abs(lv.item() - l2.item()) < 1e-5
+    worst = 0.0
     for k, p in m.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("out"):
             continue
         ref = tsd[k].grad
         err = (p.grad.cpu() - ref).abs().max().item()
         rel = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        worst = max(worst, err)
         assert err < TOL and rel < 2e-2, (k, err, rel)
+    print(f"gemm path mode={mode} n={n} B={B} T={T}: out err {(out.detach().cpu() - o2.detach()).abs().max().item():.2e}, worst grad err {worst:.2e}")

@@ -322,6 +322,18 @@ void layout_workspace(wunet_ctx* c)
         l.d = plan_conv(B, l.L, l.cin, l.cout, l.taps);
         l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
         if (l.L < 4) { l.f.ksplit = 1; l.d.ksplit = 1; }    // levels of 1-2 samples run the scalar kernels of wunet_tiny.h
+        {
+            // auto: only where the fp32 planner would launch an un-split full-width grid (enough 256-position tiles to fill
+            // the chip); forced (2): every level the kernels can run (tests of small shapes)
+            const bool big = c->h3 && l.L >= 256 && (c->h3 == 2 || (l.f.nrep == 4 && l.f.ksplit == 1));
+            l.h3f = big ? 1 : 0;
+            // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
+            l.h3d = (big && i > 0 && (c->h3 == 2 || (l.d.nrep == 4 && l.d.ksplit == 1)) && l.cin >= 16) ? 1 : 0;
+            l.h3w = l.h3d;
+            l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
+            if (l.h3f) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 255) / 256); }   // conv_h3: no split-K, 4 statistics rows per tile
+            if (l.h3d) l.d.ksplit = 1;
+        }
         l.f_rows = l.f.grid_x * WUNET_WAVES;
         l.f_wpk = wpk;
         wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
@@ -335,14 +347,6 @@ void layout_workspace(wunet_ctx* c)
         l.s = off; off += align64(l.cout);
         l.mean = off; off += align64(l.cout);
         l.rstd = off; off += align64(l.cout);
-        {
-            const bool big = c->h3 && l.L >= 256 && l.f.nrep == 4 && l.f.ksplit == 1;
-            l.h3f = big ? 1 : 0;
-            // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
-            l.h3d = (big && i > 0 && l.d.nrep == 4 && l.d.ksplit == 1 && l.cin >= 16) ? 1 : 0;
-            l.h3w = l.h3d;
-            l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
-        }
         l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
     }
     c->stats_off = off; off += align64(stats_max);
@@ -532,7 +536,7 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
 int wunet_set_h3(wunet_ctx* ctx, int enable)
 {
     if (!ctx) return fail(WUNET_E_ARG, "null ctx");
-    ctx->h3 = enable ? 1 : 0;
+    ctx->h3 = enable == 2 ? 2 : (enable ? 1 : 0);
     layout_workspace(ctx);          // sizes and offsets change: call before wunet_workspace_bytes
     return WUNET_OK;
 }

@@ -298,35 +298,41 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
         }
         __syncthreads();
         if (k + 1 < kend) WUNET_WH3_PREFETCH(k + 1)
+        // operand fragments of K step ks+1 are fetched while the MFMAs of step ks run (one wave per SIMD: nothing else
+        // would hide the LDS latency)
+        wunet_h8 ah[2][M_REP], al[2][M_REP], ph[2][3], pl[2][3];
+#define WUNET_WH3_FRAGS(KS_, BUF_)                                                                                 \
+        {                                                                                                          \
+            _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                 \
+                const wunet_half* p_ = gs + gbase + ((mt * 2) * GP + (KS_) * 32) * 8;                              \
+                ah[BUF_][mt] = wunet_ldtr8(p_, p_ + 32);                                                           \
+                al[BUF_][mt] = wunet_ldtr8(p_ + GG * GP * 8, p_ + GG * GP * 8 + 32);                               \
+            }                                                                                                      \
+            _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                        \
+                const wunet_half* p_ = xs + xbase + ((KS_) * 32 + m * 8) * 8;                                      \
+                ph[BUF_][m] = wunet_ldtr8(p_, p_ + 32);                                                            \
+                pl[BUF_][m] = wunet_ldtr8(p_ + XG * XPOS * 8, p_ + XG * XPOS * 8 + 32);                            \
+            }                                                                                                      \
+        }
+        WUNET_WH3_FRAGS(0, 0)
 #pragma unroll
         for (int ks = 0; ks < TP / 32; ++ks) {
-            wunet_h8 ah[M_REP], al[M_REP], ph[3], pl[3];
-#pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt) {
-                const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
-                ah[mt] = wunet_ldtr8(p, p + 32);
-                al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
-            }
-#pragma unroll
-            for (int m = 0; m < 3; ++m) {
-                const wunet_half* p = xs + xbase + (ks * 32 + m * 8) * 8;
-                ph[m] = wunet_ldtr8(p, p + 32);
-                pl[m] = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
-            }
+            if (ks + 1 < TP / 32) WUNET_WH3_FRAGS(ks + 1, (ks + 1) & 1)
 #define WUNET_WH3_TAP(TW_)                                                                                         \
             if (TW_ < TW && t0 + TW_ < TAPS) {                                                                     \
-                const wunet_h8 bh_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(ph);                                  \
-                const wunet_h8 bl_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(pl);                                  \
+                const wunet_h8 bh_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(ph[ks & 1]);                          \
+                const wunet_h8 bl_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(pl[ks & 1]);                          \
                 _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                             \
-                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(al[mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]);         \
-                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[mt], bl_, acc[mt][TW_ < TW ? TW_ : 0]);         \
-                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]);         \
+                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(al[ks & 1][mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]); \
+                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[ks & 1][mt], bl_, acc[mt][TW_ < TW ? TW_ : 0]); \
+                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[ks & 1][mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]); \
                 }                                                                                                  \
             }
             WUNET_WH3_TAP(0) WUNET_WH3_TAP(1) WUNET_WH3_TAP(2) WUNET_WH3_TAP(3)
             WUNET_WH3_TAP(4) WUNET_WH3_TAP(5) WUNET_WH3_TAP(6) WUNET_WH3_TAP(7)
 #undef WUNET_WH3_TAP
         }
+#undef WUNET_WH3_FRAGS
     }
 #undef WUNET_WH3_PREFETCH
 

@@ -24,8 +24,9 @@ class Engine:
     def __init__(self, lib=None, host_memory=False, h3=None):
         self.lib = lib if lib is not None else _lib.load_hip()
         self.host_memory = host_memory
-        # fp16-split GEMMs for the large levels (see include/wunet_hip.h: wunet_set_h3); WUNET_H3=1 turns it on
-        self.h3 = bool(int(os.environ.get("WUNET_H3", "0"))) if h3 is None else bool(h3)
+        # GEMM arithmetic of the large levels (include/wunet_hip.h: wunet_set_h3): 1 = fp16-split MFMA where the grid
+        # fills the chip (default), 0 = fp32 MFMA everywhere (WUNET_H3=0), 2 = fp16-split wherever it can run (tests)
+        self.h3 = int(os.environ.get("WUNET_H3", "1")) if h3 is None else int(h3)
         self._ctx = {}
         self._lock = threading.Lock()
 
@@ -42,7 +43,7 @@ class Engine:
                 h = ctypes.c_void_p()
                 self._check(self.lib.wunet_create(n_layers, ci, batch, length, ctypes.byref(h)))
                 if self.h3:
-                    self._check(self.lib.wunet_set_h3(h, 1))
+                    self._check(self.lib.wunet_set_h3(h, self.h3))
                 self._ctx[key] = h
         return h
 
