@@ -272,6 +272,7 @@ struct LayerPlan {
     // fp16-split path (large levels only)
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
+    int first;                    // encoder[0] (Cin = 1): direct fp32 kernel (conv_first_kernel)
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps;   // weight gradient uses wgrad_h3_kernel
     size_t xh, xl;                // split activated input (float offsets)
@@ -325,14 +326,16 @@ void layout_workspace(wunet_ctx* c)
         {
             // auto: only where the fp32 planner would launch an un-split full-width grid (enough 256-position tiles to fill
             // the chip); forced (2): every level the kernels can run (tests of small shapes)
+            l.first = (i == 0 && l.cin == 1 && l.taps == 15 && l.L >= 256) ? 1 : 0;
             const bool big = c->h3 && l.L >= 256 && (c->h3 == 2 || (l.f.nrep == 4 && l.f.ksplit == 1));
-            l.h3f = big ? 1 : 0;
+            l.h3f = (big && !l.first) ? 1 : 0;
             // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
             l.h3d = (big && i > 0 && (c->h3 == 2 || (l.d.nrep == 4 && l.d.ksplit == 1)) && l.cin >= 16) ? 1 : 0;
             l.h3w = l.h3d;
             l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
             if (l.h3f) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 255) / 256); }   // conv_h3: no split-K, 4 statistics rows per tile
             if (l.h3d) l.d.ksplit = 1;
+            if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
         }
         l.f_rows = l.f.grid_x * WUNET_WAVES;
         l.f_wpk = wpk;
@@ -655,7 +658,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         // 2b. conv (+ bias, + per-wave BN statistics partials) on the matrix cores
         const bool tiny = l.L < 4;
         const bool split = l.f.ksplit > 1 || tiny;      // both leave a bias-free result in the split buffer
-        if (l.h3f) {
+        if (l.first) {
+            WUNET_LAUNCH(conv_first_kernel<15>, dim3((unsigned)l.f.grid_x), dim3(WUNET_THREADS), 0, st, xin, params[4 * i], params[4 * i + 1],
+                         ws + l.z, training ? ws + c->stats_off : (float*)nullptr, c->B, l.cout, l.L, l.logL);
+        } else if (l.h3f) {
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
             wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);
             wunet_half* xl = reinterpret_cast<wunet_half*>(ws + l.xl);

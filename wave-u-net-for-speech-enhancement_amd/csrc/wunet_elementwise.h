@@ -484,6 +484,64 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------- first encoder conv (Cin = 1)
+// encoder[0] is 2*K*Cout flop per output sample against 4*Cout bytes written: HBM-bound by a wide margin, and a
+// single input channel wastes 31/32 of a matrix-core K block.  Plain fp32 FMAs: one thread = 4 consecutive samples
+// x all Cout channels (the K+3 inputs sit in registers, the weights are wave-uniform scalar loads), one 16-byte
+// store per channel; BN statistics of the bias-free conv per (wave, channel) like the MFMA kernels
+// (stats [Cout][gridDim.x*4][2], one row per wave = 256 samples).  L >= 256: a wave lies inside one batch item.
+template <int K>
+__global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* x, const float* w, const float* bias, float* out,
+                                                                    float* stats, int B, int Cout, int L, int logL)
+{
+    constexpr int PAD = K / 2, NX = ((8 + 4 + PAD + 3) / 4) * 4;          // aligned window [l0 - 8, l0 + NX - 8)
+    static_assert(PAD <= 8 && NX >= 8 + 4 + PAD, "window");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t p = ((size_t)blockIdx.x * WUNET_THREADS + threadIdx.x) * 4;
+    const int b = (int)(p >> logL), l0 = (int)(p & (size_t)(L - 1));
+    const bool live = b < B;
+    float xv[NX];
+#pragma unroll
+    for (int v = 0; v < NX / 4; ++v) {
+        const int l = l0 - 8 + 4 * v;
+        const bool ok = live && l >= 0 && l < L;
+        const wunet_f4 t = wunet_sel4(ok, wunet_ld4(x + (ok ? (size_t)b * L + l : 0)));
+        xv[4 * v] = t[0]; xv[4 * v + 1] = t[1]; xv[4 * v + 2] = t[2]; xv[4 * v + 3] = t[3];
+    }
+    const size_t rows = (size_t)gridDim.x * WUNET_WAVES, row = (size_t)blockIdx.x * WUNET_WAVES + wave;
+    for (int co = 0; co < Cout; ++co) {
+        const float* wr = w + (size_t)co * K;
+        wunet_f4 acc = wunet_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+            const float wv = wr[t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, xv[8 - PAD + t + j], acc[j]);
+        }
+        float s1 = live ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0f;
+        float s2 = live ? (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]) : 0.0f;
+        if (live) {
+            const float bv = bias ? bias[co] : 0.0f;
+            wunet_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = acc[j] + bv;
+            wunet_st4(out + ((size_t)b * Cout + co) * L + l0, o);
+        }
+        if (stats) {
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                s1 += wunet_shfl_xor(s1, m);
+                s2 += wunet_shfl_xor(s2, m);
+            }
+            if (lane == 0) {
+                float* stp = stats + ((size_t)co * rows + row) * 2;
+                stp[0] = s1;
+                stp[1] = s2;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- conv input materialisation
 // One fused pass per layer builds the tensor its conv consumes (and its weight gradient re-reads):
 //   encoder i+1 / middle : x[b,c,l] = lrelu(a[c]*z[b,c,2l] + s[c])                (unet_basic.py:13,86)

@@ -126,6 +126,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
         const size_t row = i >> (A.logL - 2);
         const int b = (int)(row / (size_t)A.C8), c8 = (int)(row - (size_t)b * A.C8);
         float v[8][4];
+        int ui0[4], ui1[4];
+        float ul0[4], ul1[4];
+        if (A.kind != 0) {                     // upsample coordinates of the 4 samples, once for the 8 channels
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wunet_up_coord(4 * l4 + j, Lh, A.up_scale, ui0[j], ui1[j], ul0[j], ul1[j]);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c8 * 8 + e;
@@ -141,11 +147,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                 const float a = A.a0[c], s = A.s0[c];
                 const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int i0, i1; float l0, l1;
-                    wunet_up_coord(4 * l4 + j, Lh, A.up_scale, i0, i1, l0, l1);
-                    v[e][j] = l0 * wunet_lrelu(a * zr[i0] + s) + l1 * wunet_lrelu(a * zr[i1] + s);
-                }
+                for (int j = 0; j < 4; ++j) v[e][j] = ul0[j] * wunet_lrelu(a * zr[ui0[j]] + s) + ul1[j] * wunet_lrelu(a * zr[ui1[j]] + s);
             } else {
                 const int cs = c - A.C0;
                 const float a = A.a1[cs], s = A.s1[cs];
