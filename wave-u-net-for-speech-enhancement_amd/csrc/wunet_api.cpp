@@ -389,7 +389,7 @@ void layout_workspace(wunet_ctx* c)
             l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
             l.h3w_nblocks = (l.cin + cib - 1) / cib;
             const long long chunks = (long long)B * l.L / 128;
-            const long long slots = 256LL * (l.h3w_mrep <= 3 ? 2 : 1);
+            const long long slots = 256LL * (l.h3w_mrep <= 2 ? 2 : 1);      // resident blocks: launch bounds of wgrad_h3_kernel
             long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
             if (ks < 1) ks = 1;
             if (ks > chunks) ks = chunks;
@@ -443,19 +443,19 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
     return 0;
 }
 
-int launch_conv_h3(int taps, int mrep, int mblocks, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh, const wunet_half* wl,
+int launch_conv_h3(int taps, int mrep, int mtiles_p, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh, const wunet_half* wl,
                    const float* bias, const float* sc, float* out, float* stats, int B, int rows, int kch, int nch, int L, hipStream_t st)
 {
+    char pname[96];
+    const double posn = (double)B * L;
     ConvH3Args a{};
     a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
-    char pname[96];
     snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d>", taps, mrep);
-    const double posn = (double)B * L;
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
     const size_t smem = (size_t)(2 * 4 * 272 + 2 * mrep * 5 * 64) * 16;
-    a.ntiles = (int)((posn + 255) / 256); a.mblocks = mblocks;
-    const dim3 grid((unsigned)(a.ntiles * mblocks));
+    a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
+    const dim3 grid((unsigned)(a.ntiles * a.mblocks));
     const int rc = wunet_launch_conv_h3(a, taps, mrep, grid, smem, st);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d (rc %d)", taps, mrep, rc);
@@ -582,14 +582,18 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     // 1. pack all forward weights into MFMA-fragment order (one launch)
     {
         PackTable tab{};
+        int nd = 0;
         for (int i = 0; i < c->NL; ++i) {
             const LayerPlan& l = c->ly[i];
-            PackDesc& d = tab.d[i];
+            if (l.h3f || l.first) continue;            // those layers do not read the fp32 pack
+            PackDesc& d = tab.d[nd++];
             d.w = params[4 * i]; d.dst = ws + c->wpkf_off + l.f_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cout; d.CP = l.f.cp; d.mtiles = l.f.mtiles_p; d.transposed = 0;
         }
-        WUNET_LAUNCH(pack_weights_kernel, dim3(128, c->NL), dim3(WUNET_THREADS), 0, st, tab);
-        WUNET_CHECK_LAUNCH();
+        if (nd > 0) {
+            WUNET_LAUNCH(pack_weights_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_CHECK_LAUNCH();
+        }
     }
     if (c->h3) {
         PackH3Table tab{};
@@ -669,7 +673,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 launch_split(xin, xh, xl, nullptr, c->B, l.cin, l.L, st);
                 WUNET_CHECK_LAUNCH();
             }
-            int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp / l.h3f_mrep, xh, xl,
+            int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], nullptr,
                                     ws + l.z, training ? ws + c->stats_off : nullptr, c->B, l.cout, l.cin, l.h3f_nch, l.L, st);
@@ -747,6 +751,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         int nd = 0;
         for (int i = 1; i < NL; ++i) {
             const LayerPlan& l = c->ly[i];
+            if (l.h3d) continue;                       // data gradient on the split pack
             PackDesc& d = tab.d[nd++];
             d.w = params[4 * i]; d.dst = ws + c->wpkb_off + l.d_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cin; d.CP = l.d.cp; d.mtiles = l.d.mtiles_p; d.transposed = 1;
@@ -880,7 +885,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             float* sc = ws + c->h3_slot + 8 + 4 * i;
             wunet_half* gh = reinterpret_cast<wunet_half*>(ws + l.gzh);
             wunet_half* gl = reinterpret_cast<wunet_half*>(ws + l.gzl);
-            int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp / l.h3d_mrep, gh, gl,
+            int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp, gh, gl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
                                     ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st);

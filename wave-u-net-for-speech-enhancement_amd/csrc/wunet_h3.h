@@ -203,8 +203,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
 // Both operands come from the split layout [B][C8][L][8] (the one the conv kernels use) by straight 16-byte copies
 // into LDS images [hi|lo][channel group][position][8]; an MFMA operand (8 consecutive positions of one channel) is two
 // transposed reads (ds_read_b64_tr_b16) of that position-major image.  Plane strides are 4 mod 16 pieces: the 32 lanes
-// of a transposed read then cover all 64 banks.  The tap shift is a compile-time funnel shift (v_alignbit) over three
-// consecutive 8-position pieces held in registers, shared by the taps of a wave.
+// of a transposed read then cover all 64 banks.  The tap shift is just a row offset of the transposed read.
 //   TAPS = 15: block = M_REP*16 co x 32 ci; wave = (ci group, tap half of 8)  -> M_REP*8 accumulator tiles
 //   TAPS =  5: block = M_REP*16 co x 64 ci; wave = ci group, all 5 taps        -> M_REP*5 accumulator tiles
 // Split-K over gridDim.x like wgrad_mfma_kernel: partial dW [gridDim.x][Cout][Cin][TAPS], reduced by wgrad_reduce_kernel.
@@ -217,7 +216,7 @@ struct WgradH3Args {
 };
 
 template <int TAPS, int M_REP>
-__global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
+__global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_kernel(WgradH3Args A)
 {
     constexpr int TP = 128, GP = 132, XPOS = 148;   // positions per chunk; plane strides (pieces) of the g_z / x images
     constexpr int WG = TAPS == 15 ? 2 : 4;          // ci groups of 16 per block
@@ -298,41 +297,31 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_kernel(WgradH3Args A)
         }
         __syncthreads();
         if (k + 1 < kend) WUNET_WH3_PREFETCH(k + 1)
-        // operand fragments of K step ks+1 are fetched while the MFMAs of step ks run (one wave per SIMD: nothing else
-        // would hide the LDS latency)
-        wunet_h8 ah[2][M_REP], al[2][M_REP], ph[2][3], pl[2][3];
-#define WUNET_WH3_FRAGS(KS_, BUF_)                                                                                 \
-        {                                                                                                          \
-            _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                 \
-                const wunet_half* p_ = gs + gbase + ((mt * 2) * GP + (KS_) * 32) * 8;                              \
-                ah[BUF_][mt] = wunet_ldtr8(p_, p_ + 32);                                                           \
-                al[BUF_][mt] = wunet_ldtr8(p_ + GG * GP * 8, p_ + GG * GP * 8 + 32);                               \
-            }                                                                                                      \
-            _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                        \
-                const wunet_half* p_ = xs + xbase + ((KS_) * 32 + m * 8) * 8;                                      \
-                ph[BUF_][m] = wunet_ldtr8(p_, p_ + 32);                                                            \
-                pl[BUF_][m] = wunet_ldtr8(p_ + XG * XPOS * 8, p_ + XG * XPOS * 8 + 32);                            \
-            }                                                                                                      \
-        }
-        WUNET_WH3_FRAGS(0, 0)
 #pragma unroll
         for (int ks = 0; ks < TP / 32; ++ks) {
-            if (ks + 1 < TP / 32) WUNET_WH3_FRAGS(ks + 1, (ks + 1) & 1)
-#define WUNET_WH3_TAP(TW_)                                                                                         \
-            if (TW_ < TW && t0 + TW_ < TAPS) {                                                                     \
-                const wunet_h8 bh_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(ph[ks & 1]);                          \
-                const wunet_h8 bl_ = wunet_funnel<OB + (TW_ < TW ? TW_ : 0)>(pl[ks & 1]);                          \
-                _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                             \
-                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(al[ks & 1][mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]); \
-                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[ks & 1][mt], bl_, acc[mt][TW_ < TW ? TW_ : 0]); \
-                    acc[mt][TW_ < TW ? TW_ : 0] = wunet_mfma16h(ah[ks & 1][mt], bh_, acc[mt][TW_ < TW ? TW_ : 0]); \
-                }                                                                                                  \
+            wunet_h8 ah[M_REP], al[M_REP];
+#pragma unroll
+            for (int mt = 0; mt < M_REP; ++mt) {
+                const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
+                ah[mt] = wunet_ldtr8(p, p + 32);
+                al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
             }
-            WUNET_WH3_TAP(0) WUNET_WH3_TAP(1) WUNET_WH3_TAP(2) WUNET_WH3_TAP(3)
-            WUNET_WH3_TAP(4) WUNET_WH3_TAP(5) WUNET_WH3_TAP(6) WUNET_WH3_TAP(7)
-#undef WUNET_WH3_TAP
+            // the tap shift is a row offset of the transposed read (rows are 16-byte pieces: any alignment)
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw) {
+                {                   // (k15: the second tap half computes a 16th, unused tap rather than branch around MFMAs)
+                    const wunet_half* p = xs + xbase + (ks * 32 + OB + tw) * 8;
+                    const wunet_h8 bh = wunet_ldtr8(p, p + 32);
+                    const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
+#pragma unroll
+                    for (int mt = 0; mt < M_REP; ++mt) {
+                        acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
+                        acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
+                        acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
+                    }
+                }
+            }
         }
-#undef WUNET_WH3_FRAGS
     }
 #undef WUNET_WH3_PREFETCH
 
