@@ -1,4 +1,2 @@
-export WUNET_NO_H3A=1
-cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_conc -o conc -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-ls $GRAFT_REPO_ROOT/gpurun_out/prof_conc | head -3
+timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | grep -E "passed|failed|error|Error" | tail -3
+timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c90-200

@@ -2,17 +2,19 @@
 #include "wunet_h3.h"
 #include "wunet_launch.h"
 
-#define WUNET_CASE(T, M)                                                                                   \
-    if (taps == T && mrep == M) {                                                                          \
-        if (WUNET_ALLOW_BIG_LDS((conv_h3_kernel<T, M>), smem) != 0) return -2;                             \
-        WUNET_LAUNCH((conv_h3_kernel<T, M>), grid, dim3(WUNET_THREADS), smem, st, a);                      \
+#define WUNET_CASE(T, M, S)                                                                                \
+    if (taps == T && mrep == M && nseg == S) {                                                             \
+        if (WUNET_ALLOW_BIG_LDS((conv_h3_kernel<T, M, S>), smem) != 0) return -2;                          \
+        WUNET_LAUNCH((conv_h3_kernel<T, M, S>), grid, dim3(WUNET_THREADS), smem, st, a);                   \
         return 0;                                                                                          \
     }
 
-int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, dim3 grid, size_t smem, hipStream_t st)
+int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st)
 {
-    WUNET_CASE(15, 2) WUNET_CASE(15, 3) WUNET_CASE(15, 4)
-    WUNET_CASE(5, 2) WUNET_CASE(5, 3) WUNET_CASE(5, 4)
+    WUNET_CASE(15, 2, 1) WUNET_CASE(15, 3, 1) WUNET_CASE(15, 4, 1)
+    WUNET_CASE(5, 2, 1) WUNET_CASE(5, 3, 1) WUNET_CASE(5, 4, 1)
+    WUNET_CASE(15, 2, 2) WUNET_CASE(15, 3, 2) WUNET_CASE(5, 2, 2) WUNET_CASE(5, 3, 2)
+    WUNET_CASE(15, 2, 4) WUNET_CASE(15, 3, 4) WUNET_CASE(5, 2, 4) WUNET_CASE(5, 3, 4)
     return -1;
 }
 

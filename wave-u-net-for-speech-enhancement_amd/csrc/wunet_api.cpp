@@ -272,6 +272,7 @@ struct LayerPlan {
     // fp16-split path (large levels only)
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
+    int h3f_sps, h3d_sps;         // K stages per split of conv_h3_kernel (the split count is f.ksplit / d.ksplit)
     int first;                    // encoder[0] (Cin = 1): direct fp32 kernel (conv_first_kernel)
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps;   // weight gradient uses wgrad_h3_kernel
@@ -313,6 +314,16 @@ int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
     return best;
 }
 
+// conv_h3_kernel split-K: with fewer than ~1.5 blocks per CU the K stages are split so that about two blocks per CU
+// exist; returns the stages per split (== nstage: no split).
+int h3_stages_per_split(int blocks, int nstage)
+{
+    if (blocks >= 384 || nstage <= 1) return nstage;
+    int ks = (512 + blocks - 1) / blocks;
+    if (ks > nstage) ks = nstage;
+    return (nstage + ks - 1) / ks;
+}
+
 void layout_workspace(wunet_ctx* c)
 {
     const int B = c->B, T = c->T, ci = c->ci;
@@ -327,14 +338,31 @@ void layout_workspace(wunet_ctx* c)
             // auto: only where the fp32 planner would launch an un-split full-width grid (enough 256-position tiles to fill
             // the chip); forced (2): every level the kernels can run (tests of small shapes)
             l.first = (i == 0 && l.cin == 1 && l.taps == 15 && l.L >= 256) ? 1 : 0;
-            const bool big = c->h3 && l.L >= 256 && (c->h3 == 2 || (l.f.nrep == 4 && l.f.ksplit == 1));
-            l.h3f = (big && !l.first) ? 1 : 0;
+            // fp16-split kernels.  auto (1): levels >= 256 samples where the fp32 planner would launch an un-split
+            // full-width grid (enough 256-position tiles to fill the chip) and the 128-sample level of a large batch
+            // (split-K fills the chip there); forced (2): every level the kernels can run (tests of small shapes)
+            const long long posn = (long long)B * l.L;
+            const bool big = c->h3 && !l.first && l.L >= 128 && posn >= 256 &&
+                             (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : posn >= 8192));
+            l.h3f = big ? 1 : 0;
             // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
-            l.h3d = (big && i > 0 && (c->h3 == 2 || (l.d.nrep == 4 && l.d.ksplit == 1)) && l.cin >= 16) ? 1 : 0;
+            l.h3d = (big && i > 0 && l.cin >= 16 && (c->h3 == 2 || l.L < 256 || (l.d.nrep == 4 && l.d.ksplit == 1))) ? 1 : 0;
             l.h3w = l.h3d;
             l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
-            if (l.h3f) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 255) / 256); }   // conv_h3: no split-K, 4 statistics rows per tile
-            if (l.h3d) l.d.ksplit = 1;
+            const int ntiles = (int)((posn + 255) / 256), ntg = l.taps / 5;
+            if (l.h3f) {
+                const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
+                l.h3f_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
+                l.h3f_sps = h3_stages_per_split(ntiles * (l.h3f_mtp / l.h3f_mrep), l.h3f_nch * ntg);
+                l.f.ksplit = (l.h3f_nch * ntg + l.h3f_sps - 1) / l.h3f_sps;
+                l.f.grid_x = ntiles;                   // 4 statistics rows per tile
+            }
+            if (l.h3d) {
+                const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
+                l.h3d_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
+                l.h3d_sps = h3_stages_per_split(ntiles * (l.h3d_mtp / l.h3d_mrep), l.h3d_nch * ntg);
+                l.d.ksplit = (l.h3d_nch * ntg + l.h3d_sps - 1) / l.h3d_sps;
+            }
             if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
         }
         l.f_rows = l.f.grid_x * WUNET_WAVES;
@@ -361,8 +389,7 @@ void layout_workspace(wunet_ctx* c)
         LayerPlan& l = c->ly[i];
         l.xh = l.xl = 0; l.h3f_wpk = l.h3d_wpk = 0;
         if (l.h3f) {
-            const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
-            l.h3f_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
+            const int c8 = (l.cin + 7) / 8;
             l.xh = off; off += align64((size_t)B * c8 * l.L * 4);
             l.xl = off; off += align64((size_t)B * c8 * l.L * 4);
             l.h3f_wpk = wfh; wfh += (size_t)l.h3f_mtp * l.h3f_nch * l.taps * 512;
@@ -418,8 +445,7 @@ void layout_workspace(wunet_ctx* c)
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
         if (!l.h3d) continue;
-        const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
-        l.h3d_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
+        const int c8 = (l.cout + 7) / 8;
         l.h3d_wpk = wbh; wbh += (size_t)l.h3d_mtp * l.h3d_nch * l.taps * 512;
         l.gzh = off; off += align64((size_t)B * c8 * l.L * 4);      // per layer: the side stream reads it late
         l.gzl = off; off += align64((size_t)B * c8 * l.L * 4);
@@ -443,22 +469,26 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
     return 0;
 }
 
-int launch_conv_h3(int taps, int mrep, int mtiles_p, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh, const wunet_half* wl,
-                   const float* bias, const float* sc, float* out, float* stats, int B, int rows, int kch, int nch, int L, hipStream_t st)
+int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
+                   const wunet_half* wl, const float* bias, const float* sc, float* out, float* stats, int B, int rows, int kch, int nch,
+                   int L, hipStream_t st)
 {
     char pname[96];
     const double posn = (double)B * L;
     ConvH3Args a{};
     a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
-    snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d>", taps, mrep);
+    const int nseg = L >= 256 ? 1 : 256 / L, nstage = nch * (taps / 5);
+    const int ksplit = (nstage + sps - 1) / sps;
+    a.stages_per_split = sps; a.split_stride = (size_t)B * rows * L;
+    snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d, %d>", taps, mrep, nseg);
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
-    const size_t smem = (size_t)(2 * 4 * 272 + 2 * mrep * 5 * 64) * 16;
+    const size_t smem = (size_t)(2 * 4 * nseg * (256 / nseg + 16) + 2 * mrep * 5 * 64) * 16;
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
-    const dim3 grid((unsigned)(a.ntiles * a.mblocks));
-    const int rc = wunet_launch_conv_h3(a, taps, mrep, grid, smem, st);
+    const dim3 grid((unsigned)(a.ntiles * a.mblocks), (unsigned)ksplit);
+    const int rc = wunet_launch_conv_h3(a, taps, mrep, nseg, grid, smem, st);
     prof_end(st);
-    if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d (rc %d)", taps, mrep, rc);
+    if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d nseg=%d (rc %d)", taps, mrep, nseg, rc);
     return 0;
 }
 
@@ -673,10 +703,11 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 launch_split(xin, xh, xl, nullptr, c->B, l.cin, l.L, st);
                 WUNET_CHECK_LAUNCH();
             }
-            int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, xh, xl,
+            int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, l.h3f_sps, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], nullptr,
-                                    ws + l.z, training ? ws + c->stats_off : nullptr, c->B, l.cout, l.cin, l.h3f_nch, l.L, st);
+                                    split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
+                                    l.cin, l.h3f_nch, l.L, st);
             if (rc) return rc;
         } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;
@@ -885,12 +916,20 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             float* sc = ws + c->h3_slot + 8 + 4 * i;
             wunet_half* gh = reinterpret_cast<wunet_half*>(ws + l.gzh);
             wunet_half* gl = reinterpret_cast<wunet_half*>(ws + l.gzl);
-            int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp, gh, gl,
+            const bool split = l.d.ksplit > 1;
+            int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp, l.h3d_sps, gh, gl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
-                                    ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st);
+                                    split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
+            if (split) {
+                const size_t nd = (size_t)c->B * l.cin * l.L;
+                size_t blocks = (nd + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (blocks > 2048) blocks = 2048;
+                WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + c->spart_off), l.d.ksplit, nd, ws + l.dx, (const float*)nullptr, 1, 0);
+                WUNET_CHECK_LAUNCH();
+            }
         } else if (i > 0 && tiny) {
             const size_t nd = (size_t)c->B * l.cin * l.L;
             WUNET_LAUNCH(tiny_conv_kernel, dim3((unsigned)((nd + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st,

@@ -14,8 +14,11 @@
 #include "wunet_dev.h"
 
 // ---------------------------------------------------------------------------- conv / data gradient
-// Implicit GEMM like conv_mfma_kernel, 256 positions x M_REP*16 rows per block (L >= 256: a tile lies inside one batch
-// item), K walked as chunks of 32 channels x groups of TG=5 taps.  Per stage the block stages the W sub-tile (and, for
+// Implicit GEMM like conv_mfma_kernel, 256 positions x M_REP*16 rows per block, K walked as chunks of 32 channels x
+// groups of TG=5 taps.  NSEG = 1: L >= 256, the tile lies inside one batch item; NSEG = 2 / 4: L = 128 / 64, the tile is
+// NSEG whole items, each with its own zero halo in the LDS image (a wave's 64 positions never straddle items).
+// Optional split-K over gridDim.y (short levels: too few position tiles to fill the chip): bias-free partial results
+// [split][B][Cout][L], summed by conv_reduce_bn_kernel / split_sum_kernel like the fp32 path.  Per stage the block stages the W sub-tile (and, for
 // the first tap group of a chunk, the x tile: 4 channel groups x 272 columns, hi and lo) and each wave issues
 // 5 taps x M_REP x 4 tiles x 3 MFMAs.
 struct ConvH3Args {
@@ -26,16 +29,19 @@ struct ConvH3Args {
     float* out;                                   // [B][Cout][L] fp32
     float* stats;                                 // nullptr or [Cout][gridDim.x*4][2]
     int B, Cout, C8, NCH, L, logL;
-    int ntiles, mblocks;                          // 1-D grid of ntiles * mblocks blocks
+    int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
+    int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
+    size_t split_stride;                          // floats between the partial results of two splits
 };
 
-template <int TAPS, int M_REP>
+template <int TAPS, int M_REP, int NSEG>
 __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_kernel(ConvH3Args A)
 {
     constexpr int PAD = TAPS / 2;
     constexpr int TG = 5;                         // taps per stage
     constexpr int NTG = TAPS / TG;
-    constexpr int COLS = 272;                     // 256 + 8 + 8
+    constexpr int LSEG = 256 / NSEG, SW = LSEG + 16;      // samples per segment, its columns incl. the halo of 8 + 8
+    constexpr int COLS = NSEG * SW;               // 272 / 288 / 320
     constexpr int XP = 2 * 4 * COLS;              // 16-byte pieces of the x tile (hi + lo)
     constexpr int XIT = (XP + WUNET_THREADS - 1) / WUNET_THREADS;     // 9
     constexpr int WPM = TG * 64;                  // pieces per (m-tile, hi|lo) sub-tile
@@ -58,9 +64,10 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
         tile = blockIdx.x / A.mblocks;
     }
     const int n0 = tile * 256;
-    const int b = n0 >> A.logL, l0 = n0 & (A.L - 1);
+    const int b = n0 >> A.logL, l0 = NSEG == 1 ? (n0 & (A.L - 1)) : 0;
     const int mt0 = mblk * M_REP;
     const int L = A.L;
+    const bool split = gridDim.y > 1;
 
     // x slots: piece f -> (which, c8 local, column)
     int xc8[XIT], xcol[XIT];
@@ -71,10 +78,15 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
         xc8[it] = f < XP ? ((r / COLS) | (f >= 4 * COLS ? 8 : 0)) : -1;       // bits 0-2: channel group in the chunk, bit 3: lo array
         xcol[it] = r % COLS;
     }
+    // column -> (batch item of the tile, sample): xseg / xl_ of slot it
+#define WUNET_H3_SEG(COL_) ((COL_) / SW)
+#define WUNET_H3_L(COL_) (l0 - 8 + ((COL_) - WUNET_H3_SEG(COL_) * SW))
     // The MFMA column j of n-tile nt is position wave*64 + 4*j + nt, so a lane ends up with 4 consecutive positions of a
     // row (one 16-byte store, 256 contiguous bytes per row and wave).  For conflict-free fragment reads the x tile is
     // kept de-interleaved in LDS: column c of a plane lives at piece (c & 3) * COLS/4 + (c >> 2).
-    const int boff = (q * COLS + wave * 16 + i16) * 8;
+    constexpr int WPS = LSEG / 64;                // waves per segment
+    const int wseg = wave / WPS, wl0 = (wave - wseg * WPS) * 64;      // this wave's batch item in the tile, first sample in it
+    const int boff = (q * COLS + ((wseg * SW + wl0) >> 2) + i16) * 8;
     const int aoff = (q * 16 + i16) * 8;
 
     wunet_f4 acc[M_REP][4];
@@ -84,17 +96,18 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
     wunet_h8 xreg[XIT], wreg[WIT];
-    const int nstage = A.NCH * NTG;
+    const int st_beg = blockIdx.y * A.stages_per_split;
+    const int nstage = (st_beg + A.stages_per_split < A.NCH * NTG) ? st_beg + A.stages_per_split : A.NCH * NTG;
 #define WUNET_H3_PREFETCH(ST_)                                                                                    \
     {                                                                                                             \
         const int ch_ = (ST_) / NTG, tg_ = (ST_) - ch_ * NTG;                                                    \
-        if (tg_ == 0) {                                                                                           \
+        if (tg_ == 0 || (ST_) == st_beg) {                                                                        \
             _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                  \
                 const int c8g_ = ch_ * 4 + (xc8[it] & 7);                                                         \
-                const int l_ = l0 - 8 + xcol[it];                                                                 \
-                const bool ok_ = xc8[it] >= 0 && c8g_ < A.C8 && b < A.B && l_ >= 0 && l_ < L;                     \
+                const int l_ = WUNET_H3_L(xcol[it]), bb_ = b + WUNET_H3_SEG(xcol[it]);                            \
+                const bool ok_ = xc8[it] >= 0 && c8g_ < A.C8 && bb_ < A.B && l_ >= 0 && l_ < L;                   \
                 const wunet_half* src_ = (xc8[it] & 8) ? A.xl : A.xh;                                             \
-                xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)b * A.C8 + c8g_) * L + l_) * 8 : 0));               \
+                xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)bb_ * A.C8 + c8g_) * L + l_) * 8 : 0));             \
             }                                                                                                     \
         }                                                                                                         \
         _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
@@ -105,18 +118,18 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
             wreg[it] = wunet_ldh8(src_ + ((((size_t)(mt0 + mt_) * A.NCH + ch_) * TAPS + tg_ * TG) * 64 + p_) * 8); \
         }                                                                                                         \
     }
-    WUNET_H3_PREFETCH(0)
+    if (st_beg < nstage) WUNET_H3_PREFETCH(st_beg)
 
-    for (int st = 0; st < nstage; ++st) {
+    for (int st = st_beg; st < nstage; ++st) {
         const int ch = st / NTG, tg = st - ch * NTG;
         __syncthreads();
-        if (tg == 0) {
+        if (tg == 0 || st == st_beg) {
 #pragma unroll
             for (int it = 0; it < XIT; ++it) {
                 const int f = tid + it * WUNET_THREADS;
                 const int c8g = ch * 4 + (xc8[it] & 7);
-                const int l = l0 - 8 + xcol[it];
-                const bool ok = xc8[it] >= 0 && c8g < A.C8 && b < A.B && l >= 0 && l < L;
+                const int l = WUNET_H3_L(xcol[it]), bb = b + WUNET_H3_SEG(xcol[it]);
+                const bool ok = xc8[it] >= 0 && c8g < A.C8 && bb < A.B && l >= 0 && l < L;
                 const int pc = (f / COLS) * COLS + (xcol[it] & 3) * (COLS / 4) + (xcol[it] >> 2);
                 if (f < XP) wunet_sth8(xs + (size_t)pc * 8, wunet_selh8(ok, xreg[it]));
             }
@@ -157,17 +170,22 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
         }
     }
 #undef WUNET_H3_PREFETCH
+#undef WUNET_H3_SEG
+#undef WUNET_H3_L
 
     // ---- epilogue (as conv_mfma_kernel): un-scale, bias, store, BN statistics of the bias-free conv
+    //      (a K split stores its bias-free partial sum; statistics then come from the reduce kernel)
     const float inv = A.sc ? A.sc[1] : 1.0f;
+    float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
+    const int bo = b + wseg;
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int l = l0 + wave * 64 + i16 * 4;
+        const int l = l0 + wl0 + i16 * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = (mt0 + mt) * 16 + q * 4 + r;
-            const float bv = (A.bias && co < A.Cout) ? A.bias[co] : 0.0f;
+            const float bv = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
             wunet_f4 o;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -176,9 +194,9 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
                 s2[r] += v * v;
                 o[nt] = v + bv;
             }
-            if (co < A.Cout && b < A.B) wunet_st4(A.out + ((size_t)b * A.Cout + co) * L + l, o);
+            if (co < A.Cout && bo < A.B) wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
         }
-        if (A.stats) {
+        if (A.stats && !split) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
