@@ -69,7 +69,8 @@ def emu_engine_h3():
 
 @pytest.mark.parametrize("n,ci,B,T,loss", [(2, 24, 1, 1024, "smooth_l1"),     # every level on the split path (L = 1024, 512, 256)
                                             (3, 16, 3, 1024, "mse"),           # 128-sample level: two-item tiles (odd batch: a half-empty tile), split-K
-                                            (1, 20, 3, 512, "l1")])            # channel counts that are not multiples of 8
+                                            (1, 20, 3, 512, "l1"),             # channel counts that are not multiples of 8
+                                            (4, 16, 5, 1024, "smooth_l1")])    # 64-sample level: four-item conv tiles, two-item wgrad chunks, odd batch
 def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
     """Same comparison as test_train_step_matches_oracle with the fp16-split path forced on: output within 2e-5, every
     gradient within 3e-4 of its tensor's largest entry (the f32-vs-f64 noise floor of these nets is 1.5e-4)."""

@@ -1,2 +1,2 @@
 timeout 900 python -m pytest tests -q -x -m gpu 2>&1 | grep -E "passed|failed|error|Error" | tail -3
-timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c90-200
+for m in 64 128 256; do echo "MINL $m"; WUNET_H3_MINL=$m timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline 2>&1 | tail -1 | cut -c90-200; done

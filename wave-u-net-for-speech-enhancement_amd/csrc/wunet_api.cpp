@@ -339,11 +339,12 @@ void layout_workspace(wunet_ctx* c)
             // the chip); forced (2): every level the kernels can run (tests of small shapes)
             l.first = (i == 0 && l.cin == 1 && l.taps == 15 && l.L >= 256) ? 1 : 0;
             // fp16-split kernels.  auto (1): levels >= 256 samples where the fp32 planner would launch an un-split
-            // full-width grid (enough 256-position tiles to fill the chip) and the 128-sample level of a large batch
-            // (split-K fills the chip there); forced (2): every level the kernels can run (tests of small shapes)
+            // full-width grid (enough 256-position tiles to fill the chip) and the 128- and 64-sample levels of a large
+            // batch (split-K fills the chip there); forced (2): every level the kernels can run (tests of small shapes)
             const long long posn = (long long)B * l.L;
-            const bool big = c->h3 && !l.first && l.L >= 128 && posn >= 256 &&
-                             (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : posn >= 8192));
+            static const int min_l = getenv("WUNET_H3_MINL") ? atoi(getenv("WUNET_H3_MINL")) : 64;   // A/B switch for measurements
+            const bool big = c->h3 && !l.first && l.L >= 64 && posn >= 256 &&
+                             (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : (l.L >= min_l && posn >= 4096)));
             l.h3f = big ? 1 : 0;
             // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
             l.h3d = (big && i > 0 && l.cin >= 16 && (c->h3 == 2 || l.L < 256 || (l.d.nrep == 4 && l.d.ksplit == 1))) ? 1 : 0;
@@ -415,7 +416,7 @@ void layout_workspace(wunet_ctx* c)
             l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "432");
             l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
             l.h3w_nblocks = (l.cin + cib - 1) / cib;
-            const long long chunks = (long long)B * l.L / 128;
+            const long long chunks = ((long long)B * l.L + 127) / 128;
             const long long slots = 256LL * (l.h3w_mrep <= 2 ? 2 : 1);      // resident blocks: launch bounds of wgrad_h3_kernel
             long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
             if (ks < 1) ks = 1;
@@ -503,10 +504,10 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
     const double posn = (double)B * l.L;
     prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
-    const int xg = l.taps == 15 ? 4 : 8;
-    const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * 132 + (size_t)2 * xg * 148 + 8) * 16;
+    const int xg = l.taps == 15 ? 4 : 8, nseg = l.L >= 128 ? 1 : 2;
+    const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * 132 + (size_t)2 * xg * (nseg == 1 ? 148 : 164) + 8) * 16;
     const dim3 grid(l.h3w_ksplit, l.h3w_nblocks, l.h3w_mblocks);
-    const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, grid, smem, st);
+    const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, grid, smem, st);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no wgrad_h3 kernel for taps=%d mrep=%d (rc %d)", l.taps, l.h3w_mrep, rc);
     return 0;

@@ -233,28 +233,32 @@ struct WgradH3Args {
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
 };
 
-template <int TAPS, int M_REP>
+template <int TAPS, int M_REP, int NSEG>
 __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_kernel(WgradH3Args A)
 {
-    constexpr int TP = 128, GP = 132, XPOS = 148;   // positions per chunk; plane strides (pieces) of the g_z / x images
+    constexpr int TP = 128, GP = 132;               // positions per chunk; plane stride (pieces) of the g_z image
+    constexpr int LSEG = TP / NSEG, SWX = LSEG + 16;        // NSEG = 2: L = 64, a chunk is two items, each with its own halo rows
+    constexpr int XROWS = NSEG == 1 ? 148 : NSEG * SWX;     // x rows staged per plane (8 halo + samples + halo)
+    constexpr int XPOS = NSEG == 1 ? 148 : 164;     // plane stride of the x image (4 mod 16)
     constexpr int WG = TAPS == 15 ? 2 : 4;          // ci groups of 16 per block
     constexpr int TW = TAPS == 15 ? 8 : 5;          // taps per wave
     constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;    // funnel offset of the wave's first tap
     constexpr int CIB = WG * 16, XG = CIB / 8, GG = M_REP * 2;
     constexpr int GPC = 2 * GG * TP;                // pieces staged per chunk: g_z, x
-    constexpr int XPC = 2 * XG * XPOS;
+    constexpr int XPC = 2 * XG * XROWS;
     constexpr int GIT = GPC / WUNET_THREADS;        // 2 * M_REP
     constexpr int XIT = (XPC + WUNET_THREADS - 1) / WUNET_THREADS;
     WUNET_DYN_SMEM(smem);
     wunet_half* gs = reinterpret_cast<wunet_half*>(smem);                      // [hi|lo][GG][GP][8]
     wunet_half* xs = gs + 2 * GG * GP * 8;                                     // [hi|lo][XG][XPOS][8] (+ slack behind it)
+    static_assert(XROWS <= XPOS, "x image");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
     const int grp = TAPS == 15 ? wave >> 1 : wave;
     const int t0 = TAPS == 15 ? (wave & 1) * 8 : 0;
     const int co0 = blockIdx.z * M_REP * 16, ci0 = blockIdx.y * CIB;
     const int L = A.L;
-    const long long nchunks = ((long long)A.B * L) / TP;
+    const long long nchunks = ((long long)A.B * L + TP - 1) / TP;      // L = 64 and an odd batch: the last chunk is half empty
     const long long kbeg = (long long)blockIdx.x * A.chunks_per_split;
     long long kend = kbeg + A.chunks_per_split;
     if (kend > nchunks) kend = nchunks;
@@ -279,18 +283,20 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
             const int f_ = tid + it * WUNET_THREADS;                                                              \
             const int pl_ = f_ / TP, pos_ = f_ - pl_ * TP;                 /* plane = which * GG + group */       \
             const int c8_ = (co0 >> 3) + (pl_ % GG);                                                              \
-            const bool ok_ = c8_ < A.GC8;                                                                         \
+            const int p_ = l0_ + pos_;                                     /* L = 64: the second item of the chunk */ \
+            const bool ok_ = c8_ < A.GC8 && b_ + (p_ >> A.logL) < A.B;                                            \
             const wunet_half* src_ = pl_ >= GG ? A.gl : A.gh;                                                     \
-            greg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)b_ * A.GC8 + c8_) * L + l0_ + pos_) * 8 : 0));          \
+            greg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)(b_ + (p_ >> A.logL)) * A.GC8 + c8_) * L + (p_ & (L - 1))) * 8 : 0)); \
         }                                                                                                         \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
             const int f_ = tid + it * WUNET_THREADS;                                                              \
-            const int pl_ = f_ / XPOS, pos_ = f_ - pl_ * XPOS;                                                    \
+            const int pl_ = f_ / XROWS, pos_ = f_ - pl_ * XROWS;                                                  \
             const int c8_ = (ci0 >> 3) + (pl_ % XG);                                                              \
-            const int l_ = l0_ - 8 + pos_;                                                                        \
-            const bool ok_ = f_ < XPC && c8_ < A.XC8 && l_ >= 0 && l_ < L;                                        \
+            const int sg_ = NSEG == 1 ? 0 : pos_ / SWX;                                                           \
+            const int l_ = (NSEG == 1 ? l0_ : 0) - 8 + pos_ - sg_ * SWX;                                          \
+            const bool ok_ = f_ < XPC && c8_ < A.XC8 && l_ >= 0 && l_ < L && b_ + sg_ < A.B;                      \
             const wunet_half* src_ = pl_ >= XG ? A.xl : A.xh;                                                     \
-            xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)b_ * A.XC8 + c8_) * L + l_) * 8 : 0));                  \
+            xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)(b_ + sg_) * A.XC8 + c8_) * L + l_) * 8 : 0));          \
         }                                                                                                         \
     }
     if (kbeg < kend) WUNET_WH3_PREFETCH(kbeg)
@@ -302,16 +308,18 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
         for (int it = 0; it < GIT; ++it) {
             const int f = tid + it * WUNET_THREADS;
             const int pl = f / TP, pos = f - pl * TP;
-            const bool ok = (co0 >> 3) + (pl % GG) < A.GC8;
+            const bool ok = (co0 >> 3) + (pl % GG) < A.GC8 && (int)((k * TP + pos) >> A.logL) < A.B;
             wunet_sth8(gs + ((size_t)pl * GP + pos) * 8, wunet_selh8(ok, greg[it]));
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
             const int f = tid + it * WUNET_THREADS;
-            const int pl = f / XPOS, pos = f - pl * XPOS;
-            const int l = l0 - 8 + pos;
-            const bool ok = (ci0 >> 3) + (pl % XG) < A.XC8 && l >= 0 && l < L;
-            if (f < XPC) wunet_sth8(xs + (size_t)f * 8, wunet_selh8(ok, xreg[it]));
+            const int pl = f / XROWS, pos = f - pl * XROWS;
+            const int sg = NSEG == 1 ? 0 : pos / SWX;
+            const int l = (NSEG == 1 ? l0 : 0) - 8 + pos - sg * SWX;
+            const int bb = (int)((k * TP) >> A.logL) + sg;
+            const bool ok = (ci0 >> 3) + (pl % XG) < A.XC8 && l >= 0 && l < L && bb < A.B;
+            if (f < XPC) wunet_sth8(xs + ((size_t)pl * XPOS + pos) * 8, wunet_selh8(ok, xreg[it]));
         }
         __syncthreads();
         if (k + 1 < kend) WUNET_WH3_PREFETCH(k + 1)
@@ -328,7 +336,8 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
                 {                   // (k15: the second tap half computes a 16th, unused tap rather than branch around MFMAs)
-                    const wunet_half* p = xs + xbase + (ks * 32 + OB + tw) * 8;
+                    const int krow = NSEG == 1 ? ks * 32 : (ks >> 1) * SWX + (ks & 1) * 32;        // first x row of this K step
+                    const wunet_half* p = xs + xbase + (krow + OB + tw) * 8;
                     const wunet_h8 bh = wunet_ldtr8(p, p + 32);
                     const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
 #pragma unroll
