@@ -356,7 +356,7 @@ void layout_workspace(wunet_ctx* c)
                 l.h3f_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
                 l.h3f_sps = h3_stages_per_split(ntiles * (l.h3f_mtp / l.h3f_mrep), l.h3f_nch * ntg);
                 l.f.ksplit = (l.h3f_nch * ntg + l.h3f_sps - 1) / l.h3f_sps;
-                l.f.grid_x = ntiles;                   // 4 statistics rows per tile
+                l.f.grid_x = ntiles;                   // one statistics row per tile (f_rows below)
             }
             if (l.h3d) {
                 const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
@@ -366,7 +366,7 @@ void layout_workspace(wunet_ctx* c)
             }
             if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
         }
-        l.f_rows = l.f.grid_x * WUNET_WAVES;
+        l.f_rows = l.h3f ? l.f.grid_x : l.f.grid_x * WUNET_WAVES;
         l.f_wpk = wpk;
         wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
         if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
@@ -904,8 +904,9 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 }
                 if (rc) return rc;
                 WUNET_CHECK_LAUNCH();
-                size_t blocks = (nw + WUNET_THREADS - 1) / WUNET_THREADS;
-                if (blocks > 2048) blocks = 2048;
+                size_t blocks = (nw / 4 + 15) / 16;                   // 16 float4 groups of outputs per block
+                if (blocks > 4096) blocks = 4096;
+                if (blocks < 1) blocks = 1;
                 WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
                              (const float*)(ws + c->wgpart_off), l.h3w ? l.h3w_ksplit : l.w.rows, nw, grads[4 * i]);
                 WUNET_CHECK_LAUNCH();

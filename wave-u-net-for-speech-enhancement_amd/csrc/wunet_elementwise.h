@@ -452,30 +452,45 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArg
 }
 
 // ---------------------------------------------------------------------------- split-K reduce of dW
+// dw[i] = sum over `splits` partial tensors, in a fixed order (deterministic).  dW is small (10^4..10^6 values) and
+// the splits are many (up to one per CU), so the work is spread over outputs AND splits: a block owns 16 float4 groups
+// of outputs; its 16 "split lanes" each sum the splits s = lane, lane+16, ... in fp32 groups of 8 and fp64 across
+// groups, and the lanes are combined in lane order through LDS in fp64.
 __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float* part, int splits, size_t n, float* dw)
 {
-    // fixed order (deterministic): groups of 8 rows in fp32, groups in fp64.  n is a multiple of 4 for every conv
-    // of this net (taps * Cin * Cout with Cout a multiple of 4 or taps*Cin...), otherwise the scalar tail handles it.
+    __shared__ double red[16][16][4];
+    const int og = threadIdx.x & 15, sl = threadIdx.x >> 4;
     const size_t n4 = n >> 2;
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
+    for (size_t base = (size_t)blockIdx.x * 16; base < n4; base += (size_t)gridDim.x * 16) {
+        const size_t i = base + og;
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        int r = 0;
-        for (; r + 8 <= splits; r += 8) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (i < n4) {
+            int r = sl;
+            for (; r + 7 * 16 < splits; r += 8 * 16) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const wunet_f4 v = wunet_ld4(part + (size_t)(r + k) * n + 4 * i);
-                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                for (int k = 0; k < 8; ++k) {
+                    const wunet_f4 v = wunet_ld4(part + (size_t)(r + k * 16) * n + 4 * i);
+                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                }
+                t0 += (double)a0; t1 += (double)a1; t2 += (double)a2; t3 += (double)a3;
             }
-            t0 += (double)a0; t1 += (double)a1; t2 += (double)a2; t3 += (double)a3;
+            for (; r < splits; r += 16) {
+                const wunet_f4 v = wunet_ld4(part + (size_t)r * n + 4 * i);
+                t0 += (double)v[0]; t1 += (double)v[1]; t2 += (double)v[2]; t3 += (double)v[3];
+            }
         }
-        for (; r < splits; ++r) {
-            const wunet_f4 v = wunet_ld4(part + (size_t)r * n + 4 * i);
-            t0 += (double)v[0]; t1 += (double)v[1]; t2 += (double)v[2]; t3 += (double)v[3];
+        __syncthreads();
+        red[sl][og][0] = t0; red[sl][og][1] = t1; red[sl][og][2] = t2; red[sl][og][3] = t3;
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+            double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { u0 += red[k][og][0]; u1 += red[k][og][1]; u2 += red[k][og][2]; u3 += red[k][og][3]; }
+            wunet_f4 o;
+            o[0] = (float)u0; o[1] = (float)u1; o[2] = (float)u2; o[3] = (float)u3;
+            wunet_st4(dw + 4 * i, o);
         }
-        wunet_f4 o;
-        o[0] = (float)t0; o[1] = (float)t1; o[2] = (float)t2; o[3] = (float)t3;
-        wunet_st4(dw + 4 * i, o);
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
         double tot = 0.0;

@@ -27,7 +27,7 @@ struct ConvH3Args {
     const float* bias;                            // [Cout] or nullptr
     const float* sc;                              // nullptr or {scale, 1/scale} of the input: the result is multiplied by sc[1]
     float* out;                                   // [B][Cout][L] fp32
-    float* stats;                                 // nullptr or [Cout][gridDim.x*4][2]
+    float* stats;                                 // nullptr or [Cout][ntiles][2]: sum, sum of squares per 256-position tile
     int B, Cout, C8, NCH, L, logL;
     int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
@@ -177,6 +177,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
     //      (a K split stores its bias-free partial sum; statistics then come from the reduce kernel)
     const float inv = A.sc ? A.sc[1] : 1.0f;
     float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
+    if (A.stats && !split) __syncthreads();       // the W tile's LDS is reused for the statistics hand-over
     const int bo = b + wseg;
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
@@ -204,12 +205,30 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
                     s1[r] += wunet_shfl_xor(s1[r], m);
                     s2[r] += wunet_shfl_xor(s2[r], m);
                 }
-                const int co = (mt0 + mt) * 16 + q * 4 + r;
-                if (i16 == 0 && co < A.Cout) {
-                    float* stp = A.stats + ((size_t)co * (A.ntiles * WUNET_WAVES) + (tile * WUNET_WAVES + wave)) * 2;
-                    stp[0] = s1[r];
-                    stp[1] = s2[r];
+                if (i16 == 0) {                                   // per-wave sums of row mt*16 + q*4 + r -> LDS
+                    float* rp = reinterpret_cast<float*>(ws) + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
+                    rp[0] = s1[r];
+                    rp[1] = s2[r];
                 }
+            }
+        }
+    }
+    // one statistics row per block (256 positions): the four waves' sums are added in wave order
+    if (A.stats && !split) {
+        __syncthreads();
+        if (tid < M_REP * 16) {
+            const float* rp = reinterpret_cast<const float*>(ws) + tid * 2;
+            float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WUNET_WAVES; ++w) {
+                t1 += rp[w * M_REP * 32];
+                t2 += rp[w * M_REP * 32 + 1];
+            }
+            const int co = mt0 * 16 + tid;
+            if (co < A.Cout) {
+                float* stp = A.stats + ((size_t)co * A.ntiles + tile) * 2;
+                stp[0] = t1;
+                stp[1] = t2;
             }
         }
     }
