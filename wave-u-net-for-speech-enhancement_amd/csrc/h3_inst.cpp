@@ -18,18 +18,17 @@ int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3
     return -1;
 }
 
-#define WUNET_WCASE(T, M, S)                                                                               \
-    if (taps == T && mrep == M && nseg == S) {                                                             \
-        if (WUNET_ALLOW_BIG_LDS((wgrad_h3_kernel<T, M, S>), smem) != 0) return -2;                         \
-        WUNET_LAUNCH((wgrad_h3_kernel<T, M, S>), grid, dim3(WUNET_THREADS), smem, st, a);                  \
+#define WUNET_WCASE(T, M, S, P)                                                                            \
+    if (taps == T && mrep == M && nseg == S && tp == P) {                                                  \
+        if (WUNET_ALLOW_BIG_LDS((wgrad_h3_kernel<T, M, S, P>), smem) != 0) return -2;                      \
+        WUNET_LAUNCH((wgrad_h3_kernel<T, M, S, P>), grid, dim3(WUNET_THREADS), smem, st, a);               \
         return 0;                                                                                          \
     }
+#define WUNET_WCASES(T, M) WUNET_WCASE(T, M, 1, 128) WUNET_WCASE(T, M, 2, 128) WUNET_WCASE(T, M, 1, 256) WUNET_WCASE(T, M, 2, 256) WUNET_WCASE(T, M, 4, 256)
 
-int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st)
+int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st)
 {
-    WUNET_WCASE(15, 2, 1) WUNET_WCASE(15, 3, 1) WUNET_WCASE(15, 4, 1)
-    WUNET_WCASE(5, 2, 1) WUNET_WCASE(5, 3, 1) WUNET_WCASE(5, 4, 1)
-    WUNET_WCASE(15, 2, 2) WUNET_WCASE(15, 3, 2) WUNET_WCASE(15, 4, 2)
-    WUNET_WCASE(5, 2, 2) WUNET_WCASE(5, 3, 2) WUNET_WCASE(5, 4, 2)
+    WUNET_WCASES(15, 2) WUNET_WCASES(15, 3) WUNET_WCASES(15, 4)
+    WUNET_WCASES(5, 2) WUNET_WCASES(5, 3) WUNET_WCASES(5, 4)
     return -1;
 }

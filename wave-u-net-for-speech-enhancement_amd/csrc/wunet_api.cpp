@@ -275,7 +275,7 @@ struct LayerPlan {
     int h3f_sps, h3d_sps;         // K stages per split of conv_h3_kernel (the split count is f.ksplit / d.ksplit)
     int first;                    // encoder[0] (Cin = 1): direct fp32 kernel (conv_first_kernel)
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
-    int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps;   // weight gradient uses wgrad_h3_kernel
+    int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps, h3w_tp;   // weight gradient uses wgrad_h3_kernel
     size_t xh, xl;                // split activated input (float offsets)
     size_t gzh, gzl;              // split scaled g_z (float offsets)
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
@@ -416,10 +416,16 @@ void layout_workspace(wunet_ctx* c)
             l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "432");
             l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
             l.h3w_nblocks = (l.cin + cib - 1) / cib;
-            const long long chunks = ((long long)B * l.L + 127) / 128;
+            // positions per K chunk.  256 doubles the time a chunk's prefetch has to land and is 5-8 % faster for the kernel
+            // alone (one block per CU, it waits on its staging), but with its 87 KB of LDS only one conv_h3 block fits
+            // beside it and the whole step (weight gradients run concurrently with the data-gradient chain) is slower:
+            // 6.76 vs 6.68 ms.  128 unless WUNET_H3W_TP=256.
+            static const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;
             const long long slots = 256LL * (l.h3w_mrep <= 2 ? 2 : 1);      // resident blocks: launch bounds of wgrad_h3_kernel
             long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
             if (ks < 1) ks = 1;
+            l.h3w_tp = tp_env == 256 ? 256 : 128;
+            const long long chunks = ((long long)B * l.L + l.h3w_tp - 1) / l.h3w_tp;
             if (ks > chunks) ks = chunks;
             l.h3w_cps = (int)((chunks + ks - 1) / ks);
             l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
@@ -504,10 +510,11 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
     const double posn = (double)B * l.L;
     prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
-    const int xg = l.taps == 15 ? 4 : 8, nseg = l.L >= 128 ? 1 : 2;
-    const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * 132 + (size_t)2 * xg * (nseg == 1 ? 148 : 164) + 8) * 16;
+    const int xg = l.taps == 15 ? 4 : 8, tp = l.h3w_tp, nseg = l.L >= tp ? 1 : tp / l.L;
+    const int xrows = nseg == 1 ? tp + 20 : nseg * (tp / nseg + 16), xpos = ((xrows + 11) / 16) * 16 + 4;
+    const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * (tp + 4) + (size_t)2 * xg * xpos + 8) * 16;
     const dim3 grid(l.h3w_ksplit, l.h3w_nblocks, l.h3w_mblocks);
-    const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, grid, smem, st);
+    const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, tp, grid, smem, st);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no wgrad_h3 kernel for taps=%d mrep=%d (rc %d)", l.taps, l.h3w_mrep, rc);
     return 0;

@@ -252,13 +252,13 @@ struct WgradH3Args {
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
 };
 
-template <int TAPS, int M_REP, int NSEG>
+template <int TAPS, int M_REP, int NSEG, int TP>
 __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_kernel(WgradH3Args A)
 {
-    constexpr int TP = 128, GP = 132;               // positions per chunk; plane stride (pieces) of the g_z image
-    constexpr int LSEG = TP / NSEG, SWX = LSEG + 16;        // NSEG = 2: L = 64, a chunk is two items, each with its own halo rows
-    constexpr int XROWS = NSEG == 1 ? 148 : NSEG * SWX;     // x rows staged per plane (8 halo + samples + halo)
-    constexpr int XPOS = NSEG == 1 ? 148 : 164;     // plane stride of the x image (4 mod 16)
+    constexpr int GP = TP + 4;                      // TP positions per chunk; plane stride (pieces) of the g_z image, 4 mod 16
+    constexpr int LSEG = TP / NSEG, SWX = LSEG + 16;        // NSEG > 1: L < TP, a chunk is NSEG items, each with its own halo rows
+    constexpr int XROWS = NSEG == 1 ? TP + 20 : NSEG * SWX; // x rows staged per plane (8 halo + samples + halo)
+    constexpr int XPOS = ((XROWS + 11) / 16) * 16 + 4;      // plane stride of the x image (4 mod 16)
     constexpr int WG = TAPS == 15 ? 2 : 4;          // ci groups of 16 per block
     constexpr int TW = TAPS == 15 ? 8 : 5;          // taps per wave
     constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;    // funnel offset of the wave's first tap
@@ -355,7 +355,8 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
                 {                   // (k15: the second tap half computes a 16th, unused tap rather than branch around MFMAs)
-                    const int krow = NSEG == 1 ? ks * 32 : (ks >> 1) * SWX + (ks & 1) * 32;        // first x row of this K step
+                    constexpr int KPS = LSEG / 32;                                                 // K steps per item
+                    const int krow = (ks / KPS) * SWX + (ks % KPS) * 32;                           // first x row of this K step
                     const wunet_half* p = xs + xbase + (krow + OB + tw) * 8;
                     const wunet_h8 bh = wunet_ldtr8(p, p + 32);
                     const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
