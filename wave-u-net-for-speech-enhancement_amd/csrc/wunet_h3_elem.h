@@ -132,6 +132,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
 #pragma unroll
             for (int j = 0; j < 4; ++j) wunet_up_coord(4 * l4 + j, Lh, A.up_scale, ui0[j], ui1[j], ul0[j], ul1[j]);
         }
+        // interior threads: ATen's coordinates of the 4 samples are (2l4-1,2l4) (2l4,2l4+1) (2l4,2l4+1) (2l4+1,2l4+2)
+        const bool win = A.kind != 0 && ui0[0] == 2 * l4 - 1 && ui1[0] == 2 * l4 && ui0[1] == 2 * l4 && ui1[1] == 2 * l4 + 1 &&
+                         ui0[2] == 2 * l4 && ui1[2] == 2 * l4 + 1 && ui0[3] == 2 * l4 + 1 && ui1[3] == 2 * l4 + 2;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c8 * 8 + e;
@@ -146,8 +149,21 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
             } else if (c < A.C0) {
                 const float a = A.a0[c], s = A.s0[c];
                 const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
+                if (win) {
+                    // the four samples 4*l4 .. 4*l4+3 read the source window [2*l4-1, 2*l4+2] (checked above against the
+                    // exact coordinates): three loads instead of eight
+                    const float w0 = zr[2 * l4 - 1], w3 = zr[2 * l4 + 2];
+                    const float2 w12 = *reinterpret_cast<const float2*>(zr + 2 * l4);
+                    const float t0 = wunet_lrelu(a * w0 + s), t1 = wunet_lrelu(a * w12.x + s), t2 = wunet_lrelu(a * w12.y + s),
+                                t3 = wunet_lrelu(a * w3 + s);
+                    v[e][0] = ul0[0] * t0 + ul1[0] * t1;
+                    v[e][1] = ul0[1] * t1 + ul1[1] * t2;
+                    v[e][2] = ul0[2] * t1 + ul1[2] * t2;
+                    v[e][3] = ul0[3] * t2 + ul1[3] * t3;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[e][j] = ul0[j] * wunet_lrelu(a * zr[ui0[j]] + s) + ul1[j] * wunet_lrelu(a * zr[ui1[j]] + s);
+                    for (int j = 0; j < 4; ++j) v[e][j] = ul0[j] * wunet_lrelu(a * zr[ui0[j]] + s) + ul1[j] * wunet_lrelu(a * zr[ui1[j]] + s);
+                }
             } else {
                 const int cs = c - A.C0;
                 const float a = A.a1[cs], s = A.s1[cs];
