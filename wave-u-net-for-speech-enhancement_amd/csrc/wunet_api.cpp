@@ -314,6 +314,13 @@ int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
     return best;
 }
 
+// floats of one split's tile-major partial dW (wgrad_h3_kernel epilogue): padded tiles
+size_t h3w_part_stride(const LayerPlan& l)
+{
+    const int tw = l.taps == 15 ? 8 : 5;
+    return (size_t)l.h3w_mblocks * l.h3w_nblocks * WUNET_WAVES * l.h3w_mrep * tw * 256;
+}
+
 // conv_h3_kernel split-K: with fewer than ~1.5 blocks per CU the K stages are split so that about two blocks per CU
 // exist; returns the stages per split (== nstage: no split).
 int h3_stages_per_split(int blocks, int nstage)
@@ -430,7 +437,7 @@ void layout_workspace(wunet_ctx* c)
             l.h3w_cps = (int)((chunks + ks - 1) / ks);
             l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
         }
-        const size_t wg = (size_t)(l.h3w ? l.h3w_ksplit : l.w.rows) * l.cout * l.cin * l.taps;
+        const size_t wg = l.h3w ? (size_t)l.h3w_ksplit * h3w_part_stride(l) : (size_t)l.w.rows * l.cout * l.cin * l.taps;
         if (wg > wgpart_max) wgpart_max = wg;
         long long sp = ((long long)B * l.L) / 4096;
         l.a_split = (int)(sp < 1 ? 1 : (sp > 64 ? 64 : sp));
@@ -506,6 +513,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
     a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
     a.chunks_per_split = l.h3w_cps;
+    a.part_stride = h3w_part_stride(l);
     char pname[96];
     snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
     const double posn = (double)B * l.L;
@@ -911,11 +919,21 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 }
                 if (rc) return rc;
                 WUNET_CHECK_LAUNCH();
-                size_t blocks = (nw / 4 + 15) / 16;                   // 16 float4 groups of outputs per block
-                if (blocks > 4096) blocks = 4096;
-                if (blocks < 1) blocks = 1;
-                WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
-                             (const float*)(ws + c->wgpart_off), l.h3w ? l.h3w_ksplit : l.w.rows, nw, grads[4 * i]);
+                if (l.h3w) {
+                    WgradH3ReduceArgs ra{};
+                    ra.part = ws + c->wgpart_off; ra.part_stride = h3w_part_stride(l); ra.splits = l.h3w_ksplit; ra.dw = grads[4 * i];
+                    ra.Cout = l.cout; ra.Cin = l.cin; ra.taps = l.taps; ra.mrep = l.h3w_mrep; ra.tw = l.taps == 15 ? 8 : 5;
+                    ra.nblocks = l.h3w_nblocks; ra.mblocks = l.h3w_mblocks; ra.cib = l.taps == 15 ? 32 : 64;
+                    size_t blocks = (ra.part_stride / 4 + 15) / 16;
+                    if (blocks > 4096) blocks = 4096;
+                    WUNET_LAUNCH(wgrad_h3_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd, ra);
+                } else {
+                    size_t blocks = (nw / 4 + 15) / 16;                   // 16 float4 groups of outputs per block
+                    if (blocks > 4096) blocks = 4096;
+                    if (blocks < 1) blocks = 1;
+                    WUNET_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, sd,
+                                 (const float*)(ws + c->wgpart_off), l.w.rows, nw, grads[4 * i]);
+                }
                 WUNET_CHECK_LAUNCH();
             }
         }

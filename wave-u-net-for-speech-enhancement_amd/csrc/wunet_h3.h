@@ -243,13 +243,15 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
 // of a transposed read then cover all 64 banks.  The tap shift is just a row offset of the transposed read.
 //   TAPS = 15: block = M_REP*16 co x 32 ci; wave = (ci group, tap half of 8)  -> M_REP*8 accumulator tiles
 //   TAPS =  5: block = M_REP*16 co x 64 ci; wave = ci group, all 5 taps        -> M_REP*5 accumulator tiles
-// Split-K over gridDim.x like wgrad_mfma_kernel: partial dW [gridDim.x][Cout][Cin][TAPS], reduced by wgrad_reduce_kernel.
+// Split-K over gridDim.x like wgrad_mfma_kernel; the partial dW of a split is stored tile-major (see the epilogue) and
+// reduced + scattered into [Cout][Cin][TAPS] by wgrad_h3_reduce_kernel.
 struct WgradH3Args {
     const wunet_half* xh; const wunet_half* xl;   // [B][XC8][L][8]
     const wunet_half* gh; const wunet_half* gl;   // [B][GC8][L][8]  scaled g_z
     const float* sc;     // {scale, 1/scale} of g_z
     float* part;
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
+    size_t part_stride;                           // floats between two splits' partial results
 };
 
 template <int TAPS, int M_REP, int NSEG, int TP>
@@ -372,15 +374,19 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
     }
 #undef WUNET_WH3_PREFETCH
 
+    // partial result, tile-major: [split][co block][ci block][wave][mt][tw][lane][4 rows] - every store is a contiguous
+    // KiB per wave (the dW layout [co][ci][tap] would be 64 scattered dwords per store); wgrad_h3_reduce_kernel sums the
+    // splits in this layout and scatters only the final dW
     const float inv = A.sc[1];
-    float* part = A.part + (size_t)blockIdx.x * A.Cout * A.Cin * TAPS;
+    float* part = A.part + (size_t)blockIdx.x * A.part_stride
+                + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * WUNET_WAVES + wave) * (M_REP * TW)) * 256 + lane * 4;
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
-        for (int tw = 0; tw < TW; ++tw)
+        for (int tw = 0; tw < TW; ++tw) {
+            wunet_f4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = co0 + mt * 16 + q * 4 + r, ci = ci0 + grp * 16 + i16, tap = t0 + tw;
-                if (co < A.Cout && ci < A.Cin && tap < TAPS) part[((size_t)co * A.Cin + ci) * TAPS + tap] = acc[mt][tw][r] * inv;
-            }
+            for (int r = 0; r < 4; ++r) o[r] = acc[mt][tw][r] * inv;
+            wunet_st4(part + (mt * TW + tw) * 256, o);
+        }
 }

@@ -41,6 +41,66 @@ __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x
     }
 }
 
+// ---------------------------------------------------------------------------- split-K reduce of wgrad_h3_kernel
+// Sums the tile-major partials of wgrad_h3_kernel over the splits (fixed order: 16 split lanes per group of outputs,
+// fp32 in groups of 8, fp64 across - like wgrad_reduce_kernel) and scatters the result into dW [Cout][Cin][TAPS].
+// One float4 of the tile-major layout = rows q*4 .. q*4+3 of one (m-tile, ci, tap).
+struct WgradH3ReduceArgs {
+    const float* part; size_t part_stride; int splits;
+    float* dw;
+    int Cout, Cin, taps, mrep, tw, nblocks, mblocks, cib;
+};
+
+__global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3ReduceArgs A)
+{
+    __shared__ double red[16][16][4];
+    const int og = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const size_t n4 = (size_t)A.mblocks * A.nblocks * WUNET_WAVES * A.mrep * A.tw * 64;
+    for (size_t base = (size_t)blockIdx.x * 16; base < n4; base += (size_t)gridDim.x * 16) {
+        const size_t i = base + og;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        if (i < n4) {
+            int r = sl;
+            for (; r + 7 * 16 < A.splits; r += 8 * 16) {
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const wunet_f4 v = wunet_ld4(A.part + (size_t)(r + k * 16) * A.part_stride + 4 * i);
+                    a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+                }
+                t0 += (double)a0; t1 += (double)a1; t2 += (double)a2; t3 += (double)a3;
+            }
+            for (; r < A.splits; r += 16) {
+                const wunet_f4 v = wunet_ld4(A.part + (size_t)r * A.part_stride + 4 * i);
+                t0 += (double)v[0]; t1 += (double)v[1]; t2 += (double)v[2]; t3 += (double)v[3];
+            }
+        }
+        __syncthreads();
+        red[sl][og][0] = t0; red[sl][og][1] = t1; red[sl][og][2] = t2; red[sl][og][3] = t3;
+        __syncthreads();
+        if (sl == 0 && i < n4) {
+            double u[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { u[0] += red[k][og][0]; u[1] += red[k][og][1]; u[2] += red[k][og][2]; u[3] += red[k][og][3]; }
+            // decode the tile-major index: i = ((((bm*nblocks + bn)*4 + wave)*mrep + mt)*tw + t)*64 + lane
+            size_t j = i;
+            const int lane = (int)(j & 63); j >>= 6;
+            const int t = (int)(j % A.tw); j /= A.tw;
+            const int mt = (int)(j % A.mrep); j /= A.mrep;
+            const int wave = (int)(j & 3); j >>= 2;
+            const int bn = (int)(j % A.nblocks), bm = (int)(j / A.nblocks);
+            const int grp = A.taps == 15 ? wave >> 1 : wave, t0 = A.taps == 15 ? (wave & 1) * 8 : 0;
+            const int ci = bn * A.cib + grp * 16 + (lane & 15), tap = t0 + t;
+            const int co = (bm * A.mrep + mt) * 16 + (lane >> 4) * 4;
+            if (ci < A.Cin && tap < A.taps) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (co + r < A.Cout) A.dw[((size_t)(co + r) * A.Cin + ci) * A.taps + tap] = (float)u[r];
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------- g_z, produced split
 // g_z = k1*g + k2*z + k3 (gz_materialize_kernel) written straight into the scaled hi / lo [B][C8][L][8] layout.  The
 // power-of-two scale comes from an upper bound of max |g_z| (bn_finalize_bwd_kernel's bound[c], max over channels) so
