@@ -1,4 +1,4 @@
-"""Copies the summaries of a `tools/_final.sh` run (gpurun_out/final) into profiles/ under a prefix and rebuilds the PMC
+"""Copies the summaries of a `tools/final_measurements.sh` run (gpurun_out/final) into profiles/ under a prefix and rebuilds the PMC
 traffic table.  Usage: python tools/collect_profiles.py r1_h3"""
 import collections, csv, json, shutil, subprocess, sys, os
 pre = sys.argv[1]; F = "gpurun_out/final"
