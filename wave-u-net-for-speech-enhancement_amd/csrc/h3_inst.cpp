@@ -28,7 +28,7 @@ int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3
 
 int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st)
 {
-    WUNET_WCASES(15, 2) WUNET_WCASES(15, 3) WUNET_WCASES(15, 4)
+    WUNET_WCASES(15, 2) WUNET_WCASES(15, 3) WUNET_WCASES(15, 4) WUNET_WCASES(15, 5) WUNET_WCASES(15, 6)
     WUNET_WCASES(5, 2) WUNET_WCASES(5, 3) WUNET_WCASES(5, 4) WUNET_WCASES(5, 5) WUNET_WCASES(5, 6)
     return -1;
 }

@@ -420,10 +420,10 @@ void layout_workspace(wunet_ctx* c)
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
         if (l.h3w) {
             const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
-            // k5: the x tile (64 channels) is the larger half of a chunk's staging and is amortised over the rows of the block:
+            // the x tile of a chunk is amortised over the rows of the block (for k5 it is the larger half of the staging):
             // prefer tall blocks (up to 6 m-tiles) unless that pads the rows by more than 15 %
             l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "432");
-            if (l.taps == 5 && !getenv("WUNET_H3W_ORDER")) {
+            if (!getenv("WUNET_H3W_ORDER")) {
                 int best_pad = 1 << 30;
                 for (int m = 2; m <= 6; ++m) if (round_up(mt, m) < best_pad) best_pad = round_up(mt, m);
                 for (int m = 6; m >= 2; --m) if (round_up(mt, m) * 100 <= best_pad * 115) { l.h3w_mrep = m; break; }
