@@ -70,10 +70,17 @@ def emu_engine_h3():
 @pytest.mark.parametrize("n,ci,B,T,loss", [(2, 24, 1, 1024, "smooth_l1"),     # every level on the split path (L = 1024, 512, 256)
                                             (3, 16, 3, 1024, "mse"),           # 128-sample level: two-item tiles (odd batch: a half-empty tile), split-K
                                             (1, 20, 3, 512, "l1"),             # channel counts that are not multiples of 8
-                                            (4, 16, 5, 1024, "smooth_l1")])    # 64-sample level: four-item conv tiles, two-item wgrad chunks, odd batch
+                                            (4, 16, 5, 1024, "smooth_l1"),     # 64-sample level: four-item conv tiles, two-item wgrad chunks, odd batch
+                                            (6, 16, 17, 1024, "mse")])         # 32- and 16-sample levels: 2 / 4 items under one wave
 def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
     """Same comparison as test_train_step_matches_oracle with the fp16-split path forced on: output within 2e-5, every
-    gradient within 3e-4 of its tensor's largest entry (the f32-vs-f64 noise floor of these nets is 1.5e-4)."""
+    gradient within 3e-4 of its tensor's largest entry (the f32-vs-f64 noise floor of these nets is 1.5e-4).  The
+    6-level net is the exception: LeakyReLU' is discontinuous, the split path's forward noise (~2e-6) flips the slope of
+    the odd activation that sits within that distance of 0, and one flipped high-gradient element moves the BatchNorm
+    sums of a few-thousand-position level by up to a percent (checked element-wise against the fp32 path: data
+    gradients agree to 1e-6, single elements of g differ by the slope factor 10) - its bar is 2 %, which an indexing
+    mistake in the two/four-items-per-wave paths (errors of order one) cannot pass."""
+    gtol = 2e-2 if n >= 6 else 3e-4
     eng = emu_engine_h3
     m, sd, pkg_loss = _build(n, ci, eng)
     noisy, clean = plan.golden_batch(B, T, 0)
@@ -102,7 +109,7 @@ def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
             assert np.all(g == 0.0), k
             continue
         scale = max(np.abs(r).max(), 1e-6)
-        assert np.abs(g - r).max() < 3e-4 * scale + 1e-6, (k, np.abs(g - r).max(), scale)
+        assert np.abs(g - r).max() < gtol * scale + 1e-6, (k, np.abs(g - r).max(), scale)
     post = m.state_dict()
     for k in plan.buffer_names(n, ci):
         assert np.abs(post[k].numpy().astype(np.float64) - sd[k]).max() < 1e-5, k

@@ -15,6 +15,8 @@ int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3
     WUNET_CASE(5, 2, 1) WUNET_CASE(5, 3, 1) WUNET_CASE(5, 4, 1)
     WUNET_CASE(15, 2, 2) WUNET_CASE(15, 3, 2) WUNET_CASE(5, 2, 2) WUNET_CASE(5, 3, 2)
     WUNET_CASE(15, 2, 4) WUNET_CASE(15, 3, 4) WUNET_CASE(5, 2, 4) WUNET_CASE(5, 3, 4)
+    WUNET_CASE(15, 2, 8) WUNET_CASE(15, 3, 8) WUNET_CASE(5, 2, 8) WUNET_CASE(5, 3, 8)
+    WUNET_CASE(15, 2, 16) WUNET_CASE(15, 3, 16) WUNET_CASE(5, 2, 16) WUNET_CASE(5, 3, 16)
     return -1;
 }
 
@@ -24,7 +26,8 @@ int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3
         WUNET_LAUNCH((wgrad_h3_kernel<T, M, S, P>), grid, dim3(WUNET_THREADS), smem, st, a);               \
         return 0;                                                                                          \
     }
-#define WUNET_WCASES(T, M) WUNET_WCASE(T, M, 1, 128) WUNET_WCASE(T, M, 2, 128) WUNET_WCASE(T, M, 1, 256) WUNET_WCASE(T, M, 2, 256) WUNET_WCASE(T, M, 4, 256)
+#define WUNET_WCASES(T, M) WUNET_WCASE(T, M, 1, 128) WUNET_WCASE(T, M, 2, 128) WUNET_WCASE(T, M, 4, 128) WUNET_WCASE(T, M, 8, 128) \
+                           WUNET_WCASE(T, M, 1, 256) WUNET_WCASE(T, M, 2, 256) WUNET_WCASE(T, M, 4, 256)
 
 int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st)
 {

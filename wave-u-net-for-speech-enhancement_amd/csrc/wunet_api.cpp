@@ -346,12 +346,12 @@ void layout_workspace(wunet_ctx* c)
             // the chip); forced (2): every level the kernels can run (tests of small shapes)
             l.first = (i == 0 && l.cin == 1 && l.taps == 15 && l.L >= 256) ? 1 : 0;
             // fp16-split kernels.  auto (1): levels >= 256 samples where the fp32 planner would launch an un-split
-            // full-width grid (enough 256-position tiles to fill the chip) and the 128- and 64-sample levels of a large
+            // full-width grid (enough 256-position tiles to fill the chip) and the 128- to 32-sample levels of a large
             // batch (split-K fills the chip there); forced (2): every level the kernels can run (tests of small shapes)
             const long long posn = (long long)B * l.L;
-            static const int min_l = getenv("WUNET_H3_MINL") ? atoi(getenv("WUNET_H3_MINL")) : 64;   // A/B switch for measurements
-            const bool big = c->h3 && !l.first && l.L >= 64 && posn >= 256 &&
-                             (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : (l.L >= min_l && posn >= 4096)));
+            static const int min_l = getenv("WUNET_H3_MINL") ? atoi(getenv("WUNET_H3_MINL")) : 32;   // A/B switch; the 16-sample level measured slower on the split kernels (6.98 vs 6.94 ms)
+            const bool big = c->h3 && !l.first && l.L >= 16 && posn >= 256 &&
+                             (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : (l.L >= min_l && posn >= 1024)));
             l.h3f = big ? 1 : 0;
             // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
             l.h3d = (big && i > 0 && l.cin >= 16 && (c->h3 == 2 || l.L < 256 || (l.d.nrep == 4 && l.d.ksplit == 1))) ? 1 : 0;

@@ -15,8 +15,8 @@
 
 // ---------------------------------------------------------------------------- conv / data gradient
 // Implicit GEMM like conv_mfma_kernel, 256 positions x M_REP*16 rows per block, K walked as chunks of 32 channels x
-// groups of TG=5 taps.  NSEG = 1: L >= 256, the tile lies inside one batch item; NSEG = 2 / 4: L = 128 / 64, the tile is
-// NSEG whole items, each with its own zero halo in the LDS image (a wave's 64 positions never straddle items).
+// groups of TG=5 taps.  NSEG = 1: L >= 256, the tile lies inside one batch item; NSEG = 2 .. 16: L = 128 .. 16, the tile is
+// NSEG whole items, each with its own zero halo in the LDS image (a lane's 4 positions never straddle items).
 // Optional split-K over gridDim.y (short levels: too few position tiles to fill the chip): bias-free partial results
 // [split][B][Cout][L], summed by conv_reduce_bn_kernel / split_sum_kernel like the fp32 path.  Per stage the block stages the W sub-tile (and, for
 // the first tap group of a chunk, the x tile: 4 channel groups x 272 columns, hi and lo) and each wave issues
@@ -84,9 +84,11 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
     // The MFMA column j of n-tile nt is position wave*64 + 4*j + nt, so a lane ends up with 4 consecutive positions of a
     // row (one 16-byte store, 256 contiguous bytes per row and wave).  For conflict-free fragment reads the x tile is
     // kept de-interleaved in LDS: column c of a plane lives at piece (c & 3) * COLS/4 + (c >> 2).
-    constexpr int WPS = LSEG / 64;                // waves per segment
-    const int wseg = wave / WPS, wl0 = (wave - wseg * WPS) * 64;      // this wave's batch item in the tile, first sample in it
-    const int boff = (q * COLS + ((wseg * SW + wl0) >> 2) + i16) * 8;
+    // this lane's 4 positions wave*64 + 4*i16 .. +3 lie in ONE batch item of the tile (LSEG >= 4): item lseg, first sample ll0
+    // (LSEG >= 64: the same item for the whole wave; the 32- and 16-sample levels put 2 / 4 items under one wave)
+    const int lpos = wave * 64 + i16 * 4;
+    const int lseg = lpos / LSEG, ll0 = lpos - lseg * LSEG;
+    const int boff = (q * COLS + ((lseg * SW + ll0) >> 2)) * 8;
     const int aoff = (q * 16 + i16) * 8;
 
     wunet_f4 acc[M_REP][4];
@@ -178,11 +180,11 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
     const float inv = A.sc ? A.sc[1] : 1.0f;
     float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
     if (A.stats && !split) __syncthreads();       // the W tile's LDS is reused for the statistics hand-over
-    const int bo = b + wseg;
+    const int bo = b + lseg;
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int l = l0 + wl0 + i16 * 4;
+        const int l = l0 + ll0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = (mt0 + mt) * 16 + q * 4 + r;
@@ -287,7 +289,9 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
     // transposed-read bases (halfs): lane (j = i16>>2, cq = i16&3) feeds row j, channels 4cq..4cq+3 of its 16-lane group
     const int tr_row = (i16 >> 2) + q * 8, tr_pl = (i16 & 3) >> 1, tr_h = (i16 & 1) * 4;
     const int gbase = (tr_pl * GP + tr_row) * 8 + tr_h;
-    const int xbase = ((grp * 2 + tr_pl) * XPOS + tr_row + t0) * 8 + tr_h;
+    // x rows: item (p / LSEG) starts at row item * SWX (its own 8 + 8 halo rows); a lane quarter's 8 positions stay in one item
+    const int qrow = ((q * 8) / LSEG) * SWX + (q * 8) % LSEG;
+    const int xbase = ((grp * 2 + tr_pl) * XPOS + (i16 >> 2) + qrow + t0) * 8 + tr_h;
 
     wunet_f4 acc[M_REP][TW];
 #pragma unroll
@@ -357,8 +361,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
                 {                   // (k15: the second tap half computes a 16th, unused tap rather than branch around MFMAs)
-                    constexpr int KPS = LSEG / 32;                                                 // K steps per item
-                    const int krow = (ks / KPS) * SWX + (ks % KPS) * 32;                           // first x row of this K step
+                    const int krow = ((ks * 32) / LSEG) * SWX + (ks * 32) % LSEG;                   // first x row of this K step
                     const wunet_half* p = xs + xbase + (krow + OB + tw) * 8;
                     const wunet_h8 bh = wunet_ldtr8(p, p + 32);
                     const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
