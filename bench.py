@@ -114,7 +114,7 @@ def main():
                          "(configs[1], the enhancement.py path) - an extra measurement, same JSON shape")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam (f1)")
     ap.add_argument("--gemm", choices=["split", "fp32"], default=None,
-                    help="GEMM arithmetic of the levels >= 256 samples: split = 3 x f16 MFMA on hi/lo fp16 halves of every fp32 "
+                    help="GEMM arithmetic of the levels >= 32 samples: split = 3 x f16 MFMA on hi/lo fp16 halves of every fp32 "
                          "operand, fp32 accumulation (default, == WUNET_H3=1); fp32 = v_mfma_f32_16x16x4_f32 everywhere (WUNET_H3=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -253,7 +253,7 @@ def main():
                       if default_net else f"{args.frame}-sample frames/sec, {args.layers}-level Wave-U-Net, mode={args.mode} (extra)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (levels >= 256 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
+            "dtype": ("f32 (levels >= 32 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
                       else "f32"),
             "data": "synthetic",
             "config": {"workload": f"unet_basic {args.layers}-level, {args.frame}-sample frames, batch={args.batch} per GPU, fp32, "

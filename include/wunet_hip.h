@@ -44,10 +44,11 @@ const char* wunet_last_error(void);
 int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out);
 void wunet_destroy(wunet_ctx* ctx);
 
-/* GEMM arithmetic of the large levels (>= 256 samples).  enable = 1: forward convs, data gradients and weight
+/* GEMM arithmetic of the levels >= 32 samples.  enable = 1: forward convs, data gradients and weight
  * gradients run as fp16-split GEMMs - every fp32 operand x is carried as hi + lo in fp16 (22 significant bits,
  * gradients pre-scaled by a power of two), a product is three v_mfma_f32_16x16x32_f16 passes with fp32 accumulation -
- * wherever the position grid fills the chip; 2: wherever the kernels can run (small test shapes); 0: fp32 MFMA
+ * wherever the position grid fills the chip (levels >= 256 samples; 128 .. 32 samples at >= 1024 positions per level,
+ * with split-K); 2: wherever the kernels can run (>= 16 samples; small test shapes); 0: fp32 MFMA
  * (v_mfma_f32_16x16x4_f32) everywhere.  Accuracy of the split path is at the fp32 noise floor, but the
  * arithmetic is not bit-identical to the fp32 path.  A new ctx starts with 0; the Python Engine turns 1 on unless
  * WUNET_H3=0.  Changes the workspace size: call before wunet_workspace_bytes.  No reference counterpart. */

@@ -1,4 +1,4 @@
-// Instantiation unit: conv_h3_kernel<TAPS, M_REP> (fp16-split GEMM path of the large levels).
+// Instantiation unit: conv_h3_kernel<TAPS, M_REP, NSEG> and wgrad_h3_kernel<TAPS, M_REP, NSEG, TP> (fp16-split GEMM path).
 #include "wunet_h3.h"
 #include "wunet_launch.h"
 

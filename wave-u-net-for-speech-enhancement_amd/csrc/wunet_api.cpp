@@ -269,7 +269,7 @@ struct LayerPlan {
     size_t f_wpk, d_wpk; // float offsets inside the forward / backward weight packs
     // workspace (float offsets)
     size_t z, a, s, mean, rstd, xin, g, dx, k1, k2, k3;
-    // fp16-split path (large levels only)
+    // fp16-split path
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
     int h3f_sps, h3d_sps;         // K stages per split of conv_h3_kernel (the split count is f.ksplit / d.ksplit)
@@ -290,7 +290,7 @@ struct wunet_ctx {
     size_t bmax_off, bound_off;   // pass A maxima / per-channel |g_z| bounds (fp16-split scale)
     size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
     int head_blocks;
-    int h3 = 0;                   // fp16-split GEMMs enabled for the large levels
+    int h3 = 0;                   // fp16-split GEMMs: 0 off, 1 where the planner wants them, 2 wherever they can run
     size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_slot;   // float offsets
     size_t h3_wf_halfs, h3_wb_halfs;
     // side stream for the weight-gradient GEMMs (off the backward's critical chain), created lazily per device

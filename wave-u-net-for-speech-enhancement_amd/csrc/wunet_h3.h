@@ -1,4 +1,4 @@
-// fp16-split ("h3") GEMM path for the large levels: every fp32 operand x is carried as hi + lo with hi, lo fp16
+// fp16-split ("h3") GEMM path for the levels >= 32 samples: every fp32 operand x is carried as hi + lo with hi, lo fp16
 // (22 significant bits together, gradients pre-scaled by a power of two into fp16's range) and a product is
 // hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16 with fp32 accumulation.  Measured against the reference this is
 // indistinguishable from fp32 (end-to-end 4e-6 on the output, <=1.1e-5 on gradients - the fp32 noise floor; a 3xbf16

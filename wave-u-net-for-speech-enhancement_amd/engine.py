@@ -24,7 +24,7 @@ class Engine:
     def __init__(self, lib=None, host_memory=False, h3=None):
         self.lib = lib if lib is not None else _lib.load_hip()
         self.host_memory = host_memory
-        # GEMM arithmetic of the large levels (include/wunet_hip.h: wunet_set_h3): 1 = fp16-split MFMA where the grid
+        # GEMM arithmetic of the levels >= 32 samples (include/wunet_hip.h: wunet_set_h3): 1 = fp16-split MFMA where the grid
         # fills the chip (default), 0 = fp32 MFMA everywhere (WUNET_H3=0), 2 = fp16-split wherever it can run (tests)
         self.h3 = int(os.environ.get("WUNET_H3", "1")) if h3 is None else int(h3)
         self._ctx = {}
