@@ -288,7 +288,7 @@ struct wunet_ctx {
     std::vector<LayerPlan> ly;
     size_t stats_off, wpkf_off, spart_off, fwd_floats;
     size_t bmax_off, bound_off;   // pass A maxima / per-channel |g_z| bounds (fp16-split scale)
-    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, total_floats;
+    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, hpart2_off, total_floats;
     int head_blocks;
     int h3 = 0;                   // fp16-split GEMMs: 0 off, 1 where the planner wants them, 2 wherever they can run
     size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_slot;   // float offsets
@@ -460,7 +460,8 @@ void layout_workspace(wunet_ctx* c)
         long long hb = ((long long)B * T) / 2048;
         c->head_blocks = (int)(hb < 1 ? 1 : (hb > 1024 ? 1024 : hb));
     }
-    c->hpart_off = off; off += align64((size_t)c->head_blocks * (ci + 2));
+    c->hpart_off = off; off += align64((size_t)c->head_blocks * 2);
+    c->hpart2_off = off; off += align64((size_t)64 * ci);          // pass A (head mode) partial head-weight gradients [a_split][ci]
     // ---- fp16-split data gradient: transposed packs, one shared split g_z buffer, scale slot
     size_t wbh = 0, gzs = 0;
     for (int i = 0; i < c->NL; ++i) {
@@ -838,9 +839,9 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         h.gh = ws + c->gh_off; h.part = ws + c->hpart_off; h.B = c->B; h.C = c->ci; h.T = c->T; h.logT = ilog2(c->T);
         WUNET_LAUNCH(head_bwd_kernel, dim3(c->head_blocks), dim3(WUNET_THREADS), 0, st, h);
         WUNET_CHECK_LAUNCH();
-        const int nh = c->ci + 2;
-        WUNET_LAUNCH(rows_sum_kernel, dim3(nh), dim3(WUNET_THREADS), 0, st,
-                     (const float*)(ws + c->hpart_off), c->head_blocks, nh, grads[4 * NL], c->ci + 1, grads[4 * NL + 1]);
+        // d(weight of the input channel), d bias; the ci per-channel weight gradients come out of the last layer's pass A
+        WUNET_LAUNCH(rows_sum_kernel, dim3(2), dim3(WUNET_THREADS), 0, st,
+                     (const float*)(ws + c->hpart_off), c->head_blocks, 2, grads[4 * NL] + c->ci, 1, grads[4 * NL + 1]);
         WUNET_CHECK_LAUNCH();
     }
 
@@ -853,9 +854,11 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         const dim3 ga(l.cout, l.a_split);
         const bool tiny = l.L < 4;
         if (i == NL - 1) {
-            p.g0 = ws + c->gh_off; p.g1 = params[4 * NL];
-            if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);
-            else WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);
+            p.g0 = ws + c->gh_off; p.g1 = params[4 * NL]; p.hpart = ws + c->hpart2_off;
+            WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);      // (the last layer has T >= 4 samples)
+            WUNET_CHECK_LAUNCH();
+            WUNET_LAUNCH(rows_sum_kernel, dim3(c->ci), dim3(WUNET_THREADS), 0, st,
+                         (const float*)(ws + c->hpart2_off), l.a_split, c->ci, grads[4 * NL], c->ci, grads[4 * NL + 1]);
         } else if (i >= n) {
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + nx.dx; p.Cg0 = nx.cin;

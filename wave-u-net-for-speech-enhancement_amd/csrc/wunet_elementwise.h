@@ -229,7 +229,7 @@ struct HeadBwdArgs {
     const float* z; const float* a; const float* s; const float* in;
     const float* out; const float* gout;
     float* gh;        // [B][T]
-    float* part;      // [gridDim.x][C+2]
+    float* part;      // [gridDim.x][2]: sum gh*input, sum gh (the per-channel sums come from pass_a_kernel<A_HEAD>)
     int B, C, T, logT;
 };
 
@@ -250,27 +250,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdArgs A)
     }
     block_sum2(sb, sin_, red);
     if (threadIdx.x == 0) {
-        A.part[(size_t)blockIdx.x * (A.C + 2) + A.C] = (float)sin_;
-        A.part[(size_t)blockIdx.x * (A.C + 2) + A.C + 1] = (float)sb;
-    }
-    __syncthreads();
-    // pass 2: per-channel sums (gh re-read from this block's own writes: same threads, same addresses)
-    for (int c = 0; c < A.C; c += 2) {
-        double s0 = 0.0, s1 = 0.0;
-        for (size_t p = beg + threadIdx.x; p < end; p += WUNET_THREADS) {
-            const size_t b = p >> A.logT, t = p & (size_t)(A.T - 1);
-            const float g = A.gh[p];
-            const float* zr = A.z + b * A.C * A.T + t;
-            s0 += (double)(g * wunet_lrelu(A.a[c] * zr[(size_t)c * A.T] + A.s[c]));
-            if (c + 1 < A.C) s1 += (double)(g * wunet_lrelu(A.a[c + 1] * zr[(size_t)(c + 1) * A.T] + A.s[c + 1]));
-        }
-        __syncthreads();
-        block_sum2(s0, s1, red);
-        if (threadIdx.x == 0) {
-            A.part[(size_t)blockIdx.x * (A.C + 2) + c] = (float)s0;
-            if (c + 1 < A.C) A.part[(size_t)blockIdx.x * (A.C + 2) + c + 1] = (float)s1;
-        }
-        __syncthreads();
+        A.part[(size_t)blockIdx.x * 2] = (float)sin_;
+        A.part[(size_t)blockIdx.x * 2 + 1] = (float)sb;
     }
 }
 
@@ -304,6 +285,7 @@ struct PassAArgs {
     float* gpre;         // out [B][C][L]
     float* part;         // [nsplit][C][2]
     float* pmax;         // nullptr or [nsplit][C][2]: max |g_pre|, max |z - mean| (bound of |g_z| for the fp16-split scale)
+    float* hpart;        // HEAD: [nsplit][C] partial head-weight gradients  sum gh * act(z_c)  (same pass over z and gh)
     const float* g0;     // HEAD: gh [B][L];  UP: dX [B][Cg0][2L];  ENC: dXdec [B][Cg0][L]
     const float* g1;     // HEAD: wh;         ENC: dXenc [B][C][L/2]
     int Cg0;             // channel count of the g0 tensor
@@ -323,7 +305,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     const size_t beg = (size_t)blockIdx.y * per, end = beg + per < total4 ? beg + per : total4;
     const float a = A.a[c], s = A.s[c], mu = A.mean[c], rstd = A.rstd[c];
     const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
-    double s1 = 0.0, s2 = 0.0;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     float mg = 0.0f, mz = 0.0f;
     for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += WUNET_THREADS) {
         const size_t p = q4 << 2;
@@ -334,7 +316,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         if (MODE == A_HEAD) {
             const wunet_f4 gh = wunet_ld4(A.g0 + (size_t)b * A.L + l);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) g[j] = wh * gh[j];
+            for (int j = 0; j < 4; ++j) {
+                g[j] = wh * gh[j];
+                s3 += (double)(gh[j] * wunet_lrelu(a * z[j] + s));      // d(head weight of channel c)
+            }
         } else if (MODE == A_ENC) {
             const wunet_f4 gd = wunet_ld4(A.g0 + ((size_t)b * A.Cg0 + A.coff + c) * A.L + l);
             const float* ge = A.g1 + ((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1);
@@ -397,6 +382,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             pm[0] = mg;
             pm[1] = mz;
         }
+    }
+    if (MODE == A_HEAD && A.hpart) {
+        double dummy = 0.0;
+        __syncthreads();
+        block_sum2(s3, dummy, red);
+        if (threadIdx.x == 0) A.hpart[(size_t)blockIdx.y * A.C + c] = (float)s3;
     }
 }
 
