@@ -115,6 +115,30 @@ def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
         assert np.abs(post[k].numpy().astype(np.float64) - sd[k]).max() < 1e-5, k
 
 
+def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3):
+    """wunet_backward_range in three buckets == one wunet_backward, bit for bit, with the split kernels forced on (per-layer
+    gradient scales and split weight packs have to survive the bucket boundaries) - the path GradSync drives."""
+    eng = emu_engine_h3
+    n, ci, B, T = 2, 24, 2, 1024
+    sd = plan.golden_state(n, ci, 0)
+    noisy, _ = plan.golden_batch(B, T, 0)
+    names, bnames = plan.param_names(n, ci), plan.buffer_names(n, ci)
+    params = [torch.from_numpy(sd[k].copy()) for k in names]
+    running = [torch.from_numpy(sd[k].copy()) for k in bnames if k.endswith("running_mean") or k.endswith("running_var")]
+    nbt = [torch.from_numpy(np.asarray(sd[k]).copy()).reshape(()).to(torch.int64) for k in bnames if k.endswith("num_batches_tracked")]
+    x = torch.from_numpy(noisy)
+    out, ws = eng.forward(n, ci, x, params, running, nbt, True, True)
+    gout = torch.from_numpy(np.random.default_rng(1).standard_normal(out.shape).astype(np.float32))
+    g1 = [torch.zeros_like(p) for p in params]
+    g2 = [torch.zeros_like(p) for p in params]
+    eng.backward(n, ci, x, params, out, gout, ws, g1)
+    nl = 2 * n + 1
+    for lb, le in [(3, nl), (1, 3), (0, 1)]:
+        eng.backward(n, ci, x, params, out, gout, ws, g2, layer_range=(lb, le))
+    for k, a, b in zip(names, g1, g2):
+        assert torch.equal(a, b), k
+
+
 def test_eval_forward_matches_oracle(emu_engine):
     n, ci, B, T = 3, 4, 2, 64
     m, sd, _ = _build(n, ci, emu_engine)

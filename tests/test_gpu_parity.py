@@ -210,9 +210,13 @@ def test_full_size_properties(pkg, dev):
             assert (post[k].cpu() - tsd[k]).abs().max().item() < 1e-5, k
 
 
-def test_backward_range_equals_full(pkg, engine, dev):
-    """wunet_backward_range in buckets (the RCCL-overlap path) == one wunet_backward call, bit for bit."""
-    n, ci, B, T = 4, 8, 2, 256
+@pytest.mark.parametrize("mode,n,ci,B,T", [(1, 4, 8, 2, 256), (2, 3, 16, 4, 2048)])
+def test_backward_range_equals_full(pkg, dev, mode, n, ci, B, T):
+    """wunet_backward_range in buckets (the RCCL-overlap path) == one wunet_backward call, bit for bit - on the fp32
+    kernels (small shape, planner mode) and with the fp16-split kernels forced on (their scale slots, split packs and
+    side-stream weight gradients have to survive the bucket boundaries)."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    engine = eng_mod.Engine(h3=mode)
     sd = plan.golden_state(n, ci, 0)
     noisy, clean = plan.golden_batch(B, T, 0)
     m = pkg.Model(n_layers=n, channels_interval=ci)
@@ -227,7 +231,8 @@ def test_backward_range_equals_full(pkg, engine, dev):
     g2 = [torch.empty_like(p) for p in params]
     engine.backward(n, ci, x, params, out, gout, ws, g1)
     nl = 2 * n + 1
-    for lb, le in [(6, nl), (3, 6), (0, 3)]:
+    cuts = [nl, (2 * nl) // 3, nl // 3, 0]
+    for le, lb in zip(cuts[:-1], cuts[1:]):
         engine.backward(n, ci, x, params, out, gout, ws, g2, layer_range=(lb, le))
     torch.cuda.synchronize()
     for a, b in zip(g1, g2):
