@@ -162,16 +162,42 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
     const float bias = A.bias[c];
     double s1 = 0.0, s2 = 0.0;
     const int total = B * L;
-    const int per = (total + gridDim.y - 1) / gridDim.y;
-    const int beg = blockIdx.y * per, end = beg + per < total ? beg + per : total;
-    for (int p = beg + tid; p < end; p += WUNET_THREADS) {
-        const int b = p >> logL, l = p & (L - 1);
-        const size_t off = ((size_t)b * A.C + c) * L + l;
-        float v = 0.0f;
-        for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * split_stride + off];
-        z[off] = v + bias;
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
+    if ((L & 3) == 0) {
+        // four samples per thread (16-byte loads and stores); every level of >= 4 samples
+        const int total4 = total >> 2;
+        const int per = (total4 + gridDim.y - 1) / gridDim.y;
+        const int beg = blockIdx.y * per, end = beg + per < total4 ? beg + per : total4;
+        for (int p4 = beg + tid; p4 < end; p4 += WUNET_THREADS) {
+            const int p = p4 << 2;
+            const int b = p >> logL, l = p & (L - 1);
+            const size_t off = ((size_t)b * A.C + c) * L + l;
+            wunet_f4 v = wunet_f4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < ksplit; ++k) {
+                const wunet_f4 t = wunet_ld4(part + (size_t)k * split_stride + off);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += t[j];
+            }
+            wunet_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[j] = v[j] + bias;
+                s1 += (double)v[j];
+                s2 += (double)v[j] * (double)v[j];
+            }
+            wunet_st4(z + off, o);
+        }
+    } else {
+        const int per = (total + gridDim.y - 1) / gridDim.y;
+        const int beg = blockIdx.y * per, end = beg + per < total ? beg + per : total;
+        for (int p = beg + tid; p < end; p += WUNET_THREADS) {
+            const int b = p >> logL, l = p & (L - 1);
+            const size_t off = ((size_t)b * A.C + c) * L + l;
+            float v = 0.0f;
+            for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * split_stride + off];
+            z[off] = v + bias;
+            s1 += (double)v;
+            s2 += (double)v * (double)v;
+        }
     }
     block_sum2(s1, s2, red);
     if (tid == 0) {
@@ -188,6 +214,23 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
 __global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* part, int ksplit, size_t n, float* out,
                                                                    const float* bias, int C, int logL)
 {
+    if ((n & 3) == 0 && (bias == nullptr || logL >= 2)) {      // 16-byte loads and stores (4 samples of one row)
+        const size_t n4 = n >> 2;
+        for (size_t i4 = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * WUNET_THREADS) {
+            const size_t i = i4 << 2;
+            wunet_f4 v = wunet_f4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < ksplit; ++k) {
+                const wunet_f4 t = wunet_ld4(part + (size_t)k * n + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] += t[j];
+            }
+            const float bv = bias ? bias[(i >> logL) % (size_t)C] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += bv;
+            wunet_st4(out + i, v);
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
         float v = 0.0f;
         for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * n + i];
@@ -195,9 +238,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* p
     }
 }
 
-// ---------------------------------------------------------------------------- output head forward
-// out[b,l] = tanh(bh + sum_c wh[c]*lrelu(a[c]*z[b,c,l]+s[c]) + wh[C]*in[b,l])
-// (reference unet_basic.py:98-99: cat([o, input]) -> Conv1d(C+1 -> 1, k=1) -> Tanh)
 struct HeadFwdArgs {
     const float* z;    // [B][C][T] raw conv output of the last decoder layer
     const float* a;
