@@ -175,6 +175,8 @@ inline wunet_h8 wunet_ldtr8(const wunet_half* p0, const wunet_half* p1)
     return r;
 }
 
+#define wunet_setprio(N_) ((void)0)
+
 inline float wunet_shfl_xor(float v, int mask)
 {
     emu::FiberState& f = emu::cur_fiber();

@@ -503,6 +503,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     const int nseg = L >= 256 ? 1 : 256 / L, nstage = nch * (taps / 5);
     const int ksplit = (nstage + sps - 1) / sps;
     a.stages_per_split = sps; a.split_stride = (size_t)B * rows * L;
+
     snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d, %d>", taps, mrep, nseg);
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
     const size_t smem = (size_t)(2 * 4 * nseg * (256 / nseg + 16) + 2 * mrep * 5 * 64) * 16;

@@ -81,6 +81,8 @@ __device__ __forceinline__ wunet_h8 wunet_funnel(const wunet_h8 (&p)[3])
     }
     return __builtin_bit_cast(wunet_h8, r);
 }
+// wave issue priority 0..3 (s_setprio)
+#define wunet_setprio(N_) __builtin_amdgcn_s_setprio(N_)
 #endif
 
 // hi/lo fp16 split of s*x (s a power of two chosen so that |s*x| stays far below 65504)
