@@ -176,6 +176,12 @@ inline wunet_h8 wunet_ldtr8(const wunet_half* p0, const wunet_half* p1)
 }
 
 #define wunet_setprio(N_) ((void)0)
+// global -> LDS DMA model: immediate copy (the emulator cannot see a missing wait; the GPU parity tests do)
+inline void wunet_dma16(const void* g, void* lds_wave_base)
+{
+    const int lane = emu::cur_fiber().tidx.x & 63;
+    std::memcpy(static_cast<char*>(lds_wave_base) + 16 * lane, g, 16);
+}
 
 inline float wunet_shfl_xor(float v, int mask)
 {

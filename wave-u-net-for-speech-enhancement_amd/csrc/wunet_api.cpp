@@ -476,7 +476,7 @@ void layout_workspace(wunet_ctx* c)
     c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
     c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
     (void)gzs;
-    c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // {scale, 1/scale} of g_z per layer (offset 8 + 4*layer)
+    c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // 8 zero floats (DMA zero page), then {scale, 1/scale} of g_z per layer (offset 8 + 4*layer)
     c->total_floats = off;
 }
 
@@ -516,22 +516,37 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
 }
 
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
-                    const float* sc, float* part, int B, hipStream_t st)
+                    const float* sc, const float* zero, float* part, int B, hipStream_t st)
 {
-    WgradH3Args a{};
-    a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
-    a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
-    a.chunks_per_split = l.h3w_cps;
-    a.part_stride = h3w_part_stride(l);
     char pname[96];
-    snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
     const double posn = (double)B * l.L;
-    prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
     const int xg = l.taps == 15 ? 4 : 8, tp = l.h3w_tp, nseg = l.L >= tp ? 1 : tp / l.L;
-    const int xrows = nseg == 1 ? tp + 20 : nseg * (tp / nseg + 16), xpos = ((xrows + 11) / 16) * 16 + 4;
-    const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * (tp + 4) + (size_t)2 * xg * xpos + 8) * 16;
     const dim3 grid(l.h3w_ksplit, l.h3w_nblocks, l.h3w_mblocks);
-    const int rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, tp, grid, smem, st);
+    // DMA-staged, double-buffered variant: whole chunks inside one item (L >= 128), both buffers within the 160 KB
+    // (blocks of two m-tiles keep the register-staged kernel: it runs two blocks per CU, which is worth more)
+    static const bool dma = getenv("WUNET_NO_H3W_DMA") == nullptr;                // A/B switch
+    const size_t smem_d = (size_t)2 * (2 * (l.h3w_mrep * 2) * 132 + 2 * xg * 148 + 8) * 16;
+    int rc;
+    if (dma && nseg == 1 && tp == 128 && smem_d <= 160 * 1024 && l.h3w_mrep >= 3 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
+        WgradH3dArgs a{};
+        a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
+        a.zero = reinterpret_cast<const wunet_half*>(zero);
+        a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
+        a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
+        snprintf(pname, sizeof pname, "wgrad_h3d_kernel<%d, %d>", l.taps, l.h3w_mrep);
+        prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
+        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, grid, smem_d, st);
+    } else {
+        WgradH3Args a{};
+        a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
+        a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
+        a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
+        snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
+        prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
+        const int xrows = nseg == 1 ? tp + 20 : nseg * (tp / nseg + 16), xpos = ((xrows + 11) / 16) * 16 + 4;
+        const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * (tp + 4) + (size_t)2 * xg * xpos + 8) * 16;
+        rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, tp, grid, smem, st);
+    }
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no wgrad_h3 kernel for taps=%d mrep=%d (rc %d)", l.taps, l.h3w_mrep, rc);
     return 0;
@@ -802,6 +817,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
     hipStream_t sd = (g_prof_on || no_side) ? st : c->side;      // the per-kernel profiler serialises everything on one stream
 
     if (layer_end == NL) {
+        if (c->h3) hipMemsetAsync(ws + c->h3_slot, 0, 8 * sizeof(float), st);     // 32 zero bytes: the zero page of the DMA-staged weight gradient
         // flipped/transposed weights for every data gradient (one launch)
         PackTable tab{};
         int nd = 0;
@@ -923,7 +939,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 if (l.h3w)
                     rc = launch_wgrad_h3(l, reinterpret_cast<const wunet_half*>(ws + l.xh), reinterpret_cast<const wunet_half*>(ws + l.xl),
                                          reinterpret_cast<const wunet_half*>(ws + l.gzh), reinterpret_cast<const wunet_half*>(ws + l.gzl),
-                                         ws + c->h3_slot + 8 + 4 * i, ws + c->wgpart_off, c->B, sd);
+                                         ws + c->h3_slot + 8 + 4 * i, ws + c->h3_slot, ws + c->wgpart_off, c->B, sd);
                 else {
                     const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
                     rc = launch_wgrad_any(l.taps, w, l.w, sd);

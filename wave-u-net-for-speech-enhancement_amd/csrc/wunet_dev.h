@@ -81,6 +81,12 @@ __device__ __forceinline__ wunet_h8 wunet_funnel(const wunet_h8 (&p)[3])
     }
     return __builtin_bit_cast(wunet_h8, r);
 }
+// global -> LDS DMA, 16 bytes per lane (global_load_lds_dwordx4): lane i's 16 bytes land at lds_wave_base + 16*i; inactive
+// lanes write nothing; the data is visible after the issuing waves' vmcnt wait + a barrier (__syncthreads does both)
+__device__ __forceinline__ void wunet_dma16(const void* g, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
 // wave issue priority 0..3 (s_setprio)
 #define wunet_setprio(N_) __builtin_amdgcn_s_setprio(N_)
 #endif

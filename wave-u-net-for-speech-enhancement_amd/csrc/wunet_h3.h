@@ -395,3 +395,145 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
             wunet_st4(part + (mt * TW + tw) * 256, o);
         }
 }
+
+// ---------------------------------------------------------------------------- weight gradient, DMA staging
+// wgrad_h3_kernel for L >= 128 with its chunk staging done by the LDS-DMA engine (global_load_lds_dwordx4): the LDS
+// images are straight copies of the split layout, so no staging registers, no VALU and no ds_write are needed, and
+// with the freed registers and LDS the tiles are DOUBLE buffered: the DMA of chunk k+1 runs while the MFMAs of chunk k
+// do, one barrier per chunk.  (This kernel runs one block per CU: nothing else hides its staging.)  Lanes whose piece
+// lies outside the tensor (halo beyond the item, channel groups beyond C8) fetch from a 16-byte zero page.
+struct WgradH3dArgs {
+    const wunet_half* xh; const wunet_half* xl;
+    const wunet_half* gh; const wunet_half* gl;
+    const wunet_half* zero;   // >= 16 zero bytes in global memory
+    const float* sc;
+    float* part;
+    int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
+    size_t part_stride;
+};
+
+template <int TAPS, int M_REP>
+__global__ __launch_bounds__(WUNET_THREADS, 1) void wgrad_h3d_kernel(WgradH3dArgs A)
+{
+    constexpr int TP = 128, GP = TP + 4, XPOS = TP + 20;          // plane strides (pieces), both 4 mod 16
+    constexpr int WG = TAPS == 15 ? 2 : 4;
+    constexpr int TW = TAPS == 15 ? 8 : 5;
+    constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;
+    constexpr int CIB = WG * 16, XG = CIB / 8, GG = M_REP * 2;
+    constexpr int GPCS = 2 * GG * GP;               // pieces of the g_z image (rows 128..131 of a plane are never read or written)
+    constexpr int XPCS = 2 * XG * XPOS;             // pieces of the x image
+    constexpr int GIT = (GPCS + WUNET_THREADS - 1) / WUNET_THREADS;
+    constexpr int XIT = (XPCS + WUNET_THREADS - 1) / WUNET_THREADS;
+    constexpr int BUF = (GPCS + XPCS + 8) * 8;      // halfs per buffer (+ slack behind the x image)
+    WUNET_DYN_SMEM(smem);
+    wunet_half* lds = reinterpret_cast<wunet_half*>(smem);            // [2][ g_z image | x image | slack ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
+    const int grp = TAPS == 15 ? wave >> 1 : wave;
+    const int t0 = TAPS == 15 ? (wave & 1) * 8 : 0;
+    const int co0 = blockIdx.z * M_REP * 16, ci0 = blockIdx.y * CIB;
+    const int L = A.L;
+    const long long nchunks = ((long long)A.B * L) / TP;
+    const long long kbeg = (long long)blockIdx.x * A.chunks_per_split;
+    long long kend = kbeg + A.chunks_per_split;
+    if (kend > nchunks) kend = nchunks;
+
+    const int tr_row = (i16 >> 2) + q * 8, tr_pl = (i16 & 3) >> 1, tr_h = (i16 & 1) * 4;
+    const int gbase = (tr_pl * GP + tr_row) * 8 + tr_h;
+    const int xbase = GPCS * 8 + ((grp * 2 + tr_pl) * XPOS + tr_row + t0) * 8 + tr_h;
+
+    // per-thread source descriptors of its pieces (chunk independent): element offset of the (plane, row) inside one
+    // batch item, or -1 for a piece that is never fetched; x rows also keep their sample offset for the halo test
+    long long gsrc[GIT]; int gsel[GIT];
+    long long xsrc[XIT]; int xrow[XIT], xsel[XIT];
+#pragma unroll
+    for (int it = 0; it < GIT; ++it) {
+        const int f = tid + it * WUNET_THREADS;
+        const int pl = f / GP, r = f - pl * GP;
+        const int c8 = (co0 >> 3) + (pl % GG);
+        gsel[it] = (f < GPCS && r < TP) ? ((c8 < A.GC8 ? 1 : 0) | (pl >= GG ? 2 : 0)) : -1;       // bit 0: real data, bit 1: lo array
+        gsrc[it] = ((long long)c8 * L + r) * 8;
+    }
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        const int f = tid + it * WUNET_THREADS;
+        const int pl = f / XPOS, r = f - pl * XPOS;
+        const int c8 = (ci0 >> 3) + (pl % XG);
+        xsel[it] = f < XPCS ? ((c8 < A.XC8 ? 1 : 0) | (pl >= XG ? 2 : 0)) : -1;
+        xrow[it] = r - 8;
+        xsrc[it] = ((long long)c8 * L + (r - 8)) * 8;
+    }
+    // issue the DMA of chunk K_ into buffer BUF_
+#define WUNET_WH3D_DMA(K_, BUF_)                                                                                  \
+    {                                                                                                             \
+        const long long n0_ = (K_) * TP;                                                                          \
+        const int b_ = (int)(n0_ >> A.logL), l0_ = (int)(n0_ & (L - 1));                                          \
+        wunet_half* dst_ = lds + (size_t)(BUF_) * BUF + (size_t)wave * 64 * 8;                                    \
+        _Pragma("unroll") for (int it = 0; it < GIT; ++it) {                                                      \
+            if (gsel[it] >= 0) {                                                                                  \
+                const wunet_half* src_ = (gsel[it] & 2) ? A.gl : A.gh;                                            \
+                const wunet_half* p_ = (gsel[it] & 1) ? src_ + (size_t)b_ * A.GC8 * L * 8 + gsrc[it] + (size_t)l0_ * 8 : A.zero; \
+                wunet_dma16(p_, dst_ + (size_t)it * WUNET_THREADS * 8);                                           \
+            }                                                                                                     \
+        }                                                                                                         \
+        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
+            if (xsel[it] >= 0) {                                                                                  \
+                const int l_ = l0_ + xrow[it];                                                                    \
+                const wunet_half* src_ = (xsel[it] & 2) ? A.xl : A.xh;                                            \
+                const wunet_half* p_ = ((xsel[it] & 1) && l_ >= 0 && l_ < L)                                      \
+                                           ? src_ + (size_t)b_ * A.XC8 * L * 8 + xsrc[it] + (size_t)l0_ * 8 : A.zero; \
+                wunet_dma16(p_, dst_ + (size_t)GPCS * 8 + (size_t)it * WUNET_THREADS * 8);                        \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+
+    wunet_f4 acc[M_REP][TW];
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) acc[mt][tw] = wunet_f4{0.f, 0.f, 0.f, 0.f};
+
+    if (kbeg < kend) WUNET_WH3D_DMA(kbeg, 0)
+    for (long long k = kbeg; k < kend; ++k) {
+        const int cur = (int)((k - kbeg) & 1);
+        __syncthreads();                           // chunk k has landed (vmcnt wait + barrier); nobody reads the other buffer any more
+        if (k + 1 < kend) WUNET_WH3D_DMA(k + 1, cur ^ 1)
+        const wunet_half* gs = lds + (size_t)cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < TP / 32; ++ks) {
+            wunet_h8 ah[M_REP], al[M_REP];
+#pragma unroll
+            for (int mt = 0; mt < M_REP; ++mt) {
+                const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
+                ah[mt] = wunet_ldtr8(p, p + 32);
+                al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
+            }
+#pragma unroll
+            for (int tw = 0; tw < TW; ++tw) {
+                const wunet_half* p = gs + xbase + (ks * 32 + OB + tw) * 8;
+                const wunet_h8 bh = wunet_ldtr8(p, p + 32);
+                const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
+#pragma unroll
+                for (int mt = 0; mt < M_REP; ++mt) {
+                    acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
+                    acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
+                    acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
+                }
+            }
+        }
+    }
+#undef WUNET_WH3D_DMA
+
+    const float inv = A.sc[1];
+    float* part = A.part + (size_t)blockIdx.x * A.part_stride
+                + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * WUNET_WAVES + wave) * (M_REP * TW)) * 256 + lane * 4;
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int tw = 0; tw < TW; ++tw) {
+            wunet_f4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = acc[mt][tw][r] * inv;
+            wunet_st4(part + (mt * TW + tw) * 256, o);
+        }
+}
