@@ -36,16 +36,17 @@ int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, in
     return -1;
 }
 
-#define WUNET_DCASE(T, M)                                                                                  \
-    if (taps == T && mrep == M) {                                                                          \
-        if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M>), smem) != 0) return -2;                           \
-        WUNET_LAUNCH((wgrad_h3d_kernel<T, M>), grid, dim3(WUNET_THREADS), smem, st, a);                    \
+#define WUNET_DCASE(T, M, D)                                                                               \
+    if (taps == T && mrep == M && db == D) {                                                               \
+        if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M, D>), smem) != 0) return -2;                        \
+        WUNET_LAUNCH((wgrad_h3d_kernel<T, M, D>), grid, dim3(WUNET_THREADS), smem, st, a);                 \
         return 0;                                                                                          \
     }
 
-int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, dim3 grid, size_t smem, hipStream_t st)
+int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st)
 {
-    WUNET_DCASE(15, 2) WUNET_DCASE(15, 3) WUNET_DCASE(15, 4) WUNET_DCASE(15, 5) WUNET_DCASE(15, 6)
-    WUNET_DCASE(5, 2) WUNET_DCASE(5, 3) WUNET_DCASE(5, 4) WUNET_DCASE(5, 5)
+    WUNET_DCASE(15, 2, true) WUNET_DCASE(15, 3, true) WUNET_DCASE(15, 4, true) WUNET_DCASE(15, 5, true) WUNET_DCASE(15, 6, true)
+    WUNET_DCASE(5, 2, true) WUNET_DCASE(5, 3, true) WUNET_DCASE(5, 4, true) WUNET_DCASE(5, 5, true)
+    WUNET_DCASE(15, 2, false) WUNET_DCASE(5, 2, false) WUNET_DCASE(5, 3, false) WUNET_DCASE(5, 4, false)
     return -1;
 }

@@ -435,10 +435,13 @@ void layout_workspace(wunet_ctx* c)
             // beside it and the whole step (weight gradients run concurrently with the data-gradient chain) is slower:
             // 6.76 vs 6.68 ms.  128 unless WUNET_H3W_TP=256.
             static const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;
-            const long long slots = 256LL * (l.h3w_mrep <= 2 ? 2 : 1);      // resident blocks: launch bounds of wgrad_h3_kernel
+            l.h3w_tp = tp_env == 256 ? 256 : 128;
+            // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 at 2
+            const bool sb2 = !getenv("WUNET_NO_H3W_SB") && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && l.h3w_tp == 128 &&
+                             ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep == 2));
+            const long long slots = 256LL * ((l.h3w_mrep <= 2 || sb2) ? 2 : 1);      // resident blocks: launch bounds of the wgrad kernels
             long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
             if (ks < 1) ks = 1;
-            l.h3w_tp = tp_env == 256 ? 256 : 128;
             const long long chunks = ((long long)B * l.L + l.h3w_tp - 1) / l.h3w_tp;
             if (ks > chunks) ks = chunks;
             l.h3w_cps = (int)((chunks + ks - 1) / ks);
@@ -527,7 +530,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     static const bool dma = getenv("WUNET_NO_H3W_DMA") == nullptr;                // A/B switch
     const size_t smem_d = (size_t)2 * (2 * (l.h3w_mrep * 2) * 132 + 2 * xg * 148 + 8) * 16;
     int rc;
-    if (dma && nseg == 1 && tp == 128 && smem_d <= 160 * 1024 && l.h3w_mrep >= 3 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
+    if (dma && nseg == 1 && tp == 128 && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
         WgradH3dArgs a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
         a.zero = reinterpret_cast<const wunet_half*>(zero);
@@ -535,7 +538,11 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
         snprintf(pname, sizeof pname, "wgrad_h3d_kernel<%d, %d>", l.taps, l.h3w_mrep);
         prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
-        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, grid, smem_d, st);
+        // two blocks per CU with a single buffer where the registers allow it (two independent blocks hide each other's
+        // waits: +18-28 % on those kernels), else one block with double-buffered tiles
+        static const bool sb = getenv("WUNET_NO_H3W_SB") == nullptr;              // A/B switch
+        const bool db = !(sb && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep == 2)));
+        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st);
     } else {
         WgradH3Args a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;

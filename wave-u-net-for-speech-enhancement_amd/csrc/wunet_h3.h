@@ -412,8 +412,8 @@ struct WgradH3dArgs {
     size_t part_stride;
 };
 
-template <int TAPS, int M_REP>
-__global__ __launch_bounds__(WUNET_THREADS, 1) void wgrad_h3d_kernel(WgradH3dArgs A)
+template <int TAPS, int M_REP, bool DB>
+__global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(WgradH3dArgs A)
 {
     constexpr int TP = 128, GP = TP + 4, XPOS = TP + 20;          // plane strides (pieces), both 4 mod 16
     constexpr int WG = TAPS == 15 ? 2 : 4;
@@ -493,11 +493,15 @@ __global__ __launch_bounds__(WUNET_THREADS, 1) void wgrad_h3d_kernel(WgradH3dArg
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) acc[mt][tw] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
-    if (kbeg < kend) WUNET_WH3D_DMA(kbeg, 0)
+    if (DB && kbeg < kend) WUNET_WH3D_DMA(kbeg, 0)
     for (long long k = kbeg; k < kend; ++k) {
-        const int cur = (int)((k - kbeg) & 1);
+        const int cur = DB ? (int)((k - kbeg) & 1) : 0;
+        if (!DB) {                                 // single buffer, two blocks per CU: the partner block computes while this DMA lands
+            __syncthreads();
+            WUNET_WH3D_DMA(k, 0)
+        }
         __syncthreads();                           // chunk k has landed (vmcnt wait + barrier); nobody reads the other buffer any more
-        if (k + 1 < kend) WUNET_WH3D_DMA(k + 1, cur ^ 1)
+        if (DB && k + 1 < kend) WUNET_WH3D_DMA(k + 1, cur ^ 1)
         const wunet_half* gs = lds + (size_t)cur * BUF;
 #pragma unroll
         for (int ks = 0; ks < TP / 32; ++ks) {
