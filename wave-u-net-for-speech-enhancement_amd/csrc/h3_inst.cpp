@@ -47,6 +47,6 @@ int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, d
 {
     WUNET_DCASE(15, 2, true) WUNET_DCASE(15, 3, true) WUNET_DCASE(15, 4, true) WUNET_DCASE(15, 5, true) WUNET_DCASE(15, 6, true)
     WUNET_DCASE(5, 2, true) WUNET_DCASE(5, 3, true) WUNET_DCASE(5, 4, true) WUNET_DCASE(5, 5, true)
-    WUNET_DCASE(15, 2, false) WUNET_DCASE(5, 2, false) WUNET_DCASE(5, 3, false) WUNET_DCASE(5, 4, false)
+    WUNET_DCASE(15, 2, false) WUNET_DCASE(15, 3, false) WUNET_DCASE(5, 2, false) WUNET_DCASE(5, 3, false) WUNET_DCASE(5, 4, false)
     return -1;
 }

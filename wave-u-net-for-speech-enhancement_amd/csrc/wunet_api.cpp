@@ -420,14 +420,9 @@ void layout_workspace(wunet_ctx* c)
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
         if (l.h3w) {
             const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
-            // the x tile of a chunk is amortised over the rows of the block (for k5 it is the larger half of the staging):
-            // prefer tall blocks (up to 6 m-tiles) unless that pads the rows by more than 15 %
-            l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "432");
-            if (!getenv("WUNET_H3W_ORDER")) {
-                int best_pad = 1 << 30;
-                for (int m = 2; m <= 6; ++m) if (round_up(mt, m) < best_pad) best_pad = round_up(mt, m);
-                for (int m = 6; m >= 2; --m) if (round_up(mt, m) * 100 <= best_pad * 115) { l.h3w_mrep = m; break; }
-            }
+            // 3 or 2 m-tiles per block: those DMA-staged kernels fit two blocks per CU, and two independent blocks beat taller
+            // single blocks (weight gradients 1.25 -> 1.14 ms per step; the register-staged kernel preferred 5-6 m-tiles)
+            l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "32");
             l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
             l.h3w_nblocks = (l.cin + cib - 1) / cib;
             // positions per K chunk.  256 doubles the time a chunk's prefetch has to land and is 5-8 % faster for the kernel
@@ -436,9 +431,9 @@ void layout_workspace(wunet_ctx* c)
             // 6.76 vs 6.68 ms.  128 unless WUNET_H3W_TP=256.
             static const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;
             l.h3w_tp = tp_env == 256 ? 256 : 128;
-            // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 at 2
+            // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 up to 3
             const bool sb2 = !getenv("WUNET_NO_H3W_SB") && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && l.h3w_tp == 128 &&
-                             ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep == 2));
+                             ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
             const long long slots = 256LL * ((l.h3w_mrep <= 2 || sb2) ? 2 : 1);      // resident blocks: launch bounds of the wgrad kernels
             long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
             if (ks < 1) ks = 1;
@@ -541,7 +536,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
         // two blocks per CU with a single buffer where the registers allow it (two independent blocks hide each other's
         // waits: +18-28 % on those kernels), else one block with double-buffered tiles
         static const bool sb = getenv("WUNET_NO_H3W_SB") == nullptr;              // A/B switch
-        const bool db = !(sb && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep == 2)));
+        const bool db = !(sb && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3)));
         rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st);
     } else {
         WgradH3Args a{};
