@@ -35,7 +35,7 @@ struct ConvH3Args {
 };
 
 template <int TAPS, int M_REP, int NSEG>
-__global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_kernel(ConvH3Args A)
+__global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
 {
     constexpr int PAD = TAPS / 2;
     constexpr int TG = 5;                         // taps per stage
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
-    wunet_h8 xreg[XIT], wreg[WIT];
+    wunet_h8 xreg[XIT];
     const int st_beg = blockIdx.y * A.stages_per_split;
     const int nstage = (st_beg + A.stages_per_split < A.NCH * NTG) ? st_beg + A.stages_per_split : A.NCH * NTG;
 #define WUNET_H3_PREFETCH(ST_)                                                                                    \
@@ -111,13 +111,6 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
                 const wunet_half* src_ = (xc8[it] & 8) ? A.xl : A.xh;                                             \
                 xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)bb_ * A.C8 + c8g_) * L + l_) * 8 : 0));             \
             }                                                                                                     \
-        }                                                                                                         \
-        _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
-            const int f_ = tid + it * WUNET_THREADS;                                                              \
-            const int g_ = f_ < WP ? f_ : 0;                                                                      \
-            const int which_ = g_ / (M_REP * WPM), r_ = g_ % (M_REP * WPM), mt_ = r_ / WPM, p_ = r_ % WPM;        \
-            const wunet_half* src_ = which_ ? A.wl : A.wh;                                                        \
-            wreg[it] = wunet_ldh8(src_ + ((((size_t)(mt0 + mt_) * A.NCH + ch_) * TAPS + tg_ * TG) * 64 + p_) * 8); \
         }                                                                                                         \
     }
     if (st_beg < nstage) WUNET_H3_PREFETCH(st_beg)
@@ -137,10 +130,19 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 3 ? 2 : 1)) void conv_h3_k
                 if (f < XP) wunet_sth8(xs + (size_t)pc * 8, wunet_selh8(ok, xreg[it]));
             }
         }
+        {
+            // the W sub-tile of this stage straight into LDS (the pack is the LDS image: lane-linear DMA); the partner block
+            // on the CU computes while it lands
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int f = tid + it * WUNET_THREADS;
-            if (f < WP) wunet_sth8(ws + (size_t)f * 8, wreg[it]);
+            for (int it = 0; it < WIT; ++it) {
+                const int f = tid + it * WUNET_THREADS;
+                if (f < WP) {
+                    const int which = f / (M_REP * WPM), r = f % (M_REP * WPM), mt = r / WPM, p = r % WPM;
+                    const wunet_half* src = which ? A.wl : A.wh;
+                    wunet_dma16(src + ((((size_t)(mt0 + mt) * A.NCH + ch) * TAPS + tg * TG) * 64 + p) * 8,
+                                ws + ((size_t)it * WUNET_THREADS + wave * 64) * 8);
+                }
+            }
         }
         __syncthreads();
         if (st + 1 < nstage) WUNET_H3_PREFETCH(st + 1)
