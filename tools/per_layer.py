@@ -14,7 +14,7 @@ for i,(n,ci,co,t) in enumerate(layers):
     else: L=16384>>(11-int(n.split('.')[1]))
     Ls.append(L)
 fw=[r for r in seq if 'conv_h3' in r['Kernel_Name'] or 'conv_mfma' in r['Kernel_Name'] or 'conv_first' in r['Kernel_Name']]
-wg=[r for r in seq if ('wgrad_h3_kernel' in r['Kernel_Name'] or 'wgrad_mfma' in r['Kernel_Name'])]
+wg=[r for r in seq if ('wgrad_h3_kernel' in r['Kernel_Name'] or 'wgrad_h3d_kernel' in r['Kernel_Name'] or 'wgrad_mfma' in r['Kernel_Name'])]
 dur=lambda r:(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
 fwd=fw[:25]; dg=fw[25:][::-1]   # dgrad in reverse order: layers 24..1
 print("layer              L    cin cout | fwd us  (TF)  hbm-floor | dgrad us (TF) | wgrad us (TF)")
