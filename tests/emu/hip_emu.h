@@ -176,6 +176,7 @@ inline wunet_h8 wunet_ldtr8(const wunet_half* p0, const wunet_half* p1)
 }
 
 #define wunet_setprio(N_) ((void)0)
+inline void wunet_dma_wait() {}
 // global -> LDS DMA model: immediate copy (the emulator cannot see a missing wait; the GPU parity tests do)
 inline void wunet_dma16(const void* g, void* lds_wave_base)
 {

@@ -87,6 +87,9 @@ __device__ __forceinline__ void wunet_dma16(const void* g, void* lds_wave_base)
 {
     __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// all of this wave's DMAs have landed (explicit: __syncthreads() also drains vmcnt while a DMA is in flight, but the data
+// hazard should not hang on a compiler habit)
+__device__ __forceinline__ void wunet_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wave issue priority 0..3 (s_setprio)
 #define wunet_setprio(N_) __builtin_amdgcn_s_setprio(N_)
 #endif

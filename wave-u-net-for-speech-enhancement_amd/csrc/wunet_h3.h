@@ -144,6 +144,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
                 }
             }
         }
+        wunet_dma_wait();
         __syncthreads();
         if (st + 1 < nstage) WUNET_H3_PREFETCH(st + 1)
         wunet_setprio(3);                         // MFMA phase ahead of the co-resident block's staging instructions (measured: -1 % per step)
@@ -502,6 +503,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(
             __syncthreads();
             WUNET_WH3D_DMA(k, 0)
         }
+        wunet_dma_wait();
         __syncthreads();                           // chunk k has landed (vmcnt wait + barrier); nobody reads the other buffer any more
         if (DB && k + 1 < kend) WUNET_WH3D_DMA(k + 1, cur ^ 1)
         const wunet_half* gs = lds + (size_t)cur * BUF;
