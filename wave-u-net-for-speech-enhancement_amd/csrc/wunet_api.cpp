@@ -275,6 +275,7 @@ struct LayerPlan {
     int h3f_sps, h3d_sps;         // K stages per split of conv_h3_kernel (the split count is f.ksplit / d.ksplit)
     int first;                    // encoder[0] (Cin = 1): direct fp32 kernel (conv_first_kernel)
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
+    int skip_from;                // decoder layer: > 0 = its skip half is written by the operand pass of encoder-side layer skip_from
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps, h3w_tp;   // weight gradient uses wgrad_h3_kernel
     size_t xh, xl;                // split activated input (float offsets)
     size_t gzh, gzl;              // split scaled g_z (float offsets)
@@ -387,6 +388,16 @@ void layout_workspace(wunet_ctx* c)
         l.mean = off; off += align64(l.cout);
         l.rstd = off; off += align64(l.cout);
         l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
+    }
+    // the operand pass of encoder-side layer i (decimation of its producer's activation) also writes that activation at full
+    // resolution into the split input of the decoder layer that concatenates it: one read of the producer's z instead of two
+    for (int i = 0; i < c->NL; ++i) c->ly[i].skip_from = 0;
+    for (int i = 1; i <= c->n; ++i) {
+        const int dj = 2 * c->n - i + 1;
+        LayerPlan& e = c->ly[i];
+        LayerPlan& d = c->ly[dj];
+        if (e.kind == LK_DECIM && d.kind == LK_UPCAT && e.h3x && d.h3x && d.src1 == e.src0 && d.c0 % 8 == 0 && !getenv("WUNET_NO_SKIP_FUSE"))
+            d.skip_from = i;
     }
     c->stats_off = off; off += align64(stats_max);
     c->wpkf_off = off; off += align64(wpk);
@@ -702,12 +713,21 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 ph.xh = reinterpret_cast<wunet_half*>(ws + l.xh); ph.xl = reinterpret_cast<wunet_half*>(ws + l.xl);
                 ph.B = c->B; ph.C0 = l.c0; ph.C1 = l.cin - l.c0; ph.C8 = (l.cin + 7) / 8; ph.L = l.L; ph.logL = l.logL;
                 ph.kind = l.kind == LK_UPCAT ? 1 : 0;
+                ph.up_only = (l.kind == LK_UPCAT && l.skip_from > 0) ? 1 : 0;
+                if (l.kind == LK_DECIM) {
+                    const int dj = 2 * c->n - i + 1;             // the decoder layer that concatenates this pass's producer
+                    if (dj < c->NL && c->ly[dj].skip_from == i) {
+                        const LayerPlan& dl = c->ly[dj];
+                        ph.sh = reinterpret_cast<wunet_half*>(ws + dl.xh); ph.sl = reinterpret_cast<wunet_half*>(ws + dl.xl);
+                        ph.SC8 = (dl.cin + 7) / 8; ph.sc8off = dl.c0 / 8;
+                    }
+                }
                 if (l.kind == LK_UPCAT) {
                     const LayerPlan& k = c->ly[l.src1];
                     ph.z1 = ws + k.z; ph.a1 = ws + k.a; ph.s1 = ws + k.s;
                     ph.up_scale = (float)(l.L / 2 - 1) / (float)(l.L - 1);
                 }
-                const size_t nt = (size_t)c->B * ph.C8 * (l.L / 4);
+                const size_t nt = (size_t)c->B * (ph.up_only ? ph.C0 / 8 : ph.C8) * (l.L / 4);
                 size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (hb > 16384) hb = 16384;
                 WUNET_LAUNCH(prep_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, ph);

@@ -175,17 +175,26 @@ struct PrepH3Args {
     wunet_half* xh; wunet_half* xl;
     int B, C0, C1, C8, L, logL, kind;
     float up_scale;
+    // kind 0 only: the same pass over the producer's z also writes its full-resolution activation - the skip half of the
+    // decoder input that concatenates it (unet_basic.py:95) - into that layer's split arrays at channel group sc8off
+    wunet_half* sh; wunet_half* sl; int SC8, sc8off;
+    int up_only;         // kind 1: the skip half was written by the encoder-side pass: only the C0/8 upsampled groups
 };
 
 __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
 {
     const int l4n = A.L >> 2, Lh = A.L >> 1, C = A.C0 + A.C1;
-    const size_t total = (size_t)A.B * A.C8 * l4n;
+    const int ngrp = A.up_only ? A.C0 / 8 : A.C8;            // channel groups this launch produces
+    const size_t total = (size_t)A.B * ngrp * l4n;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int l4 = (int)(i & (size_t)(l4n - 1));
-        const size_t row = i >> (A.logL - 2);
-        const int b = (int)(row / (size_t)A.C8), c8 = (int)(row - (size_t)b * A.C8);
+        const size_t grow = i >> (A.logL - 2);
+        const int b = (int)(grow / (size_t)ngrp), c8 = (int)(grow - (size_t)b * ngrp);
+        const size_t row = (size_t)b * A.C8 + c8;
         float v[8][4];
+        float vo[8][4];                        // kind 0 with a skip destination: the odd samples (v holds the even ones)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vo[e][0] = vo[e][1] = vo[e][2] = vo[e][3] = 0.0f;
         int ui0[4], ui1[4];
         float ul0[4], ul1[4];
         if (A.kind != 0) {                     // upsample coordinates of the 4 samples, once for the 8 channels
@@ -206,6 +215,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                 const wunet_f4 u = wunet_ld4(src), w = wunet_ld4(src + 4);
                 v[e][0] = wunet_lrelu(a * u[0] + s); v[e][1] = wunet_lrelu(a * u[2] + s);
                 v[e][2] = wunet_lrelu(a * w[0] + s); v[e][3] = wunet_lrelu(a * w[2] + s);
+                if (A.sh) {
+                    vo[e][0] = wunet_lrelu(a * u[1] + s); vo[e][1] = wunet_lrelu(a * u[3] + s);
+                    vo[e][2] = wunet_lrelu(a * w[1] + s); vo[e][3] = wunet_lrelu(a * w[3] + s);
+                }
             } else if (c < A.C0) {
                 const float a = A.a0[c], s = A.s0[c];
                 const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
@@ -246,6 +259,25 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
             }
             wunet_sth8(ph + 8 * j, h);
             wunet_sth8(pl + 8 * j, l);
+        }
+        if (A.kind == 0 && A.sh) {
+            // skip half of the decoder input at the producer's resolution (2L): samples 8*l4 .. 8*l4+7 = even/odd interleaved
+            const size_t srow = (size_t)b * A.SC8 + A.sc8off + c8;
+            wunet_half* qh = A.sh + (srow * (size_t)(2 * A.L) + 8 * (size_t)l4) * 8;
+            wunet_half* ql = A.sl + (srow * (size_t)(2 * A.L) + 8 * (size_t)l4) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                wunet_h8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    wunet_half a, d;
+                    wunet_split_h((j & 1) ? vo[e][j >> 1] : v[e][j >> 1], a, d);
+                    wunet_put_half(h, e, a);
+                    wunet_put_half(l, e, d);
+                }
+                wunet_sth8(qh + 8 * j, h);
+                wunet_sth8(ql + 8 * j, l);
+            }
         }
     }
 }
