@@ -175,6 +175,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    enqueue = time.perf_counter() - t0          # host time to issue the K steps (the GPU runs behind it)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -266,6 +267,7 @@ def main():
             "gemm": "split" if split_gemm else "fp32",
             "whole_step_algorithmic_hbm_frac": per_gpu_fps * step_bytes / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,
+            "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(result))
