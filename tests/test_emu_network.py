@@ -115,6 +115,14 @@ def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
         assert np.abs(post[k].numpy().astype(np.float64) - sd[k]).max() < 1e-5, k
 
 
+def test_fp16_split_four_rows_per_wave(emu_engine_h3, monkeypatch):
+    """conv_h3_kernel<TAPS, 4, 1> (64 output rows per block; the planner picks it for the large 5-tap layers of the
+    12-level net, too large for the emulator) forced through the A/B switches on a net whose m-tile counts are 4 and 8."""
+    monkeypatch.setenv("WUNET_H3_ORDER", "432")
+    monkeypatch.setenv("WUNET_H3D_ORDER", "432")
+    test_fp16_split_train_step_matches_oracle(emu_engine_h3, 2, 32, 2, 1024, "mse")
+
+
 def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3):
     """wunet_backward_range in three buckets == one wunet_backward, bit for bit, with the split kernels forced on (per-layer
     gradient scales and split weight packs have to survive the bucket boundaries) - the path GradSync drives."""

@@ -305,7 +305,7 @@ namespace {
 int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
 {
     int best = 2, best_pad = 1 << 30;
-    const char* ord = getenv(env);                    // A/B switch for measurements
+    const char* ord = env ? getenv(env) : nullptr;    // A/B switch for measurements
     if (!ord) ord = dflt;
     for (const char* p = ord; *p; ++p) {
         const int m = *p - '0';
@@ -313,6 +313,15 @@ int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
         if (pad < best_pad) { best_pad = pad; best = m; }
     }
     return best;
+}
+
+// Preference order of the accumulator rows per wave (16 * M_REP output rows per block) of conv_h3_kernel.  3 and 2 keep the
+// most blocks resident; 4 (no padding for 8 m-tiles, a third fewer re-reads of the x tile) wins on the 5-tap layers while
+// the grid still has two blocks for every CU (measured per layer: decoder.7 forward 73.6 -> 65.9 us, decoder.10 data
+// gradient 166.7 -> 141.4 us; at 256 samples the same choice leaves CUs idle: 35.7 -> 49.6 us) and is neutral on 15 taps.
+const char* h3_order(int taps, int L, int ntiles, int mtiles)
+{
+    return (taps == 5 && L >= 256 && (long long)ntiles * ((mtiles + 3) / 4) >= 512) ? "432" : "32";
 }
 
 // floats of one split's tile-major partial dW (wgrad_h3_kernel epilogue): padded tiles
@@ -359,16 +368,16 @@ void layout_workspace(wunet_ctx* c)
             l.h3w = l.h3d;
             l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
             const int ntiles = (int)((posn + 255) / 256), ntg = l.taps / 5;
-            if (l.h3f) {
+            if (l.h3f) {                               // (4 accumulator rows per wave only exist un-segmented: L >= 256)
                 const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
-                l.h3f_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
+                l.h3f_mrep = pick_mrep_h3(mt, l.L >= 256 ? "WUNET_H3_ORDER" : nullptr, h3_order(l.taps, l.L, ntiles, mt)); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
                 l.h3f_sps = h3_stages_per_split(ntiles * (l.h3f_mtp / l.h3f_mrep), l.h3f_nch * ntg);
                 l.f.ksplit = (l.h3f_nch * ntg + l.h3f_sps - 1) / l.h3f_sps;
                 l.f.grid_x = ntiles;                   // one statistics row per tile (f_rows below)
             }
             if (l.h3d) {
                 const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
-                l.h3d_mrep = pick_mrep_h3(mt, "WUNET_H3_ORDER", "32"); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
+                l.h3d_mrep = pick_mrep_h3(mt, l.L >= 256 ? "WUNET_H3D_ORDER" : nullptr, h3_order(l.taps, l.L, ntiles, mt)); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
                 l.h3d_sps = h3_stages_per_split(ntiles * (l.h3d_mtp / l.h3d_mrep), l.h3d_nch * ntg);
                 l.d.ksplit = (l.h3d_nch * ntg + l.h3d_sps - 1) / l.h3d_sps;
             }

@@ -8,8 +8,20 @@
 #else
 #define WUNET_LAUNCH(kern, grid, block, smem, stream, ...) hipLaunchKernelGGL(kern, grid, block, smem, stream, __VA_ARGS__)
 // gfx950 has 160 KiB of LDS per CU; more than 64 KiB of dynamic LDS must be requested per kernel
-#define WUNET_ALLOW_BIG_LDS(kern, smem) \
-    ((smem) > 64 * 1024 ? (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem)) : 0)
+// (granted once per kernel and device, remembered: hipFuncSetAttribute on every launch costs host time)
+#define WUNET_ALLOW_BIG_LDS(kern, smem)                                                                    \
+    ([&]() -> int {                                                                                        \
+        static size_t granted[64];                                                                         \
+        static const bool always = getenv("WUNET_ATTR_ALWAYS") != nullptr;     /* A/B switch */            \
+        if ((size_t)(smem) <= 64 * 1024) return 0;                                                         \
+        int dev = 0;                                                                                       \
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, granted[0] = 0;             \
+        if (!always && (size_t)(smem) <= granted[dev]) return 0;                                           \
+        const int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem));   \
+        if (e == 0) granted[dev] = (size_t)(smem);                                                         \
+        return e;                                                                                          \
+    }())
 #endif
 
 // One translation unit per tap count keeps hipcc builds parallel.  Return 0 when a kernel
