@@ -442,7 +442,10 @@ void layout_workspace(wunet_ctx* c)
             const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
             // 3 or 2 m-tiles per block: those DMA-staged kernels fit two blocks per CU, and two independent blocks beat taller
             // single blocks (weight gradients 1.25 -> 1.14 ms per step; the register-staged kernel preferred 5-6 m-tiles)
-            l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", "32");
+            // per-layer sweep (profiles/r1_h3_rows_per_wave_sweep.txt): 4 where 5 taps divide evenly at >= 256 samples
+            // (decoder.7: 79 -> 68 us); 2 on the short 15-tap levels (encoder.6/7/9: 44 -> 39, 32 -> 29, 21 -> 18 us)
+            const char* w_order = (l.taps == 5 && l.L >= 256 && mt % 4 == 0) ? "432" : (l.taps == 15 && l.L <= 256) ? "2" : "32";
+            l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", w_order);
             l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
             l.h3w_nblocks = (l.cin + cib - 1) / cib;
             // positions per K chunk.  256 doubles the time a chunk's prefetch has to land and is 5-8 % faster for the kernel
