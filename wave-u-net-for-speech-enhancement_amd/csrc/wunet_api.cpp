@@ -742,7 +742,18 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 const size_t nt = (size_t)c->B * (ph.up_only ? ph.C0 / 8 : ph.C8) * (l.L / 4);
                 size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (hb > 16384) hb = 16384;
-                WUNET_LAUNCH(prep_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, ph);
+                static const bool prep4 = getenv("WUNET_PREP4") != nullptr;               // A/B switch
+                if (prep4) {
+                    WUNET_LAUNCH(prep4_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, ph);
+                } else {
+                    size_t hb1 = (nt * 4 + WUNET_THREADS - 1) / WUNET_THREADS;            // one thread per sample and channel group
+                    if (hb1 > 65536) hb1 = 65536;
+                    const dim3 g1((unsigned)hb1), t1(WUNET_THREADS);
+                    if (ph.up_only) WUNET_LAUNCH((prep_h3_kernel<3>), g1, t1, 0, st, ph);
+                    else if (ph.kind) WUNET_LAUNCH((prep_h3_kernel<2>), g1, t1, 0, st, ph);
+                    else if (ph.sh) WUNET_LAUNCH((prep_h3_kernel<1>), g1, t1, 0, st, ph);
+                    else WUNET_LAUNCH((prep_h3_kernel<0>), g1, t1, 0, st, ph);
+                }
             } else if (l.L < 4) {
                 if (l.kind == LK_UPCAT) {
                     const LayerPlan& k = c->ly[l.src1];
