@@ -302,6 +302,13 @@ struct wunet_ctx {
 
 namespace {
 
+// blocks per layer of the weight-pack launches (grid-stride loops inside)
+unsigned pack_gx()
+{
+    static const int gx = getenv("WUNET_PACK_GX") ? atoi(getenv("WUNET_PACK_GX")) : 512;       // A/B switch
+    return (unsigned)(gx > 0 ? gx : 512);
+}
+
 int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
 {
     int best = 2, best_pad = 1 << 30;
@@ -686,7 +693,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cout; d.CP = l.f.cp; d.mtiles = l.f.mtiles_p; d.transposed = 0;
         }
         if (nd > 0) {
-            WUNET_LAUNCH(pack_weights_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_LAUNCH(pack_weights_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
             WUNET_CHECK_LAUNCH();
         }
     }
@@ -703,7 +710,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cout; d.kch = l.cin; d.mtiles = l.h3f_mtp; d.nch = l.h3f_nch; d.transposed = 0;
         }
         if (nd > 0) {
-            WUNET_LAUNCH(pack_h3_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
             WUNET_CHECK_LAUNCH();
         }
     }
@@ -874,7 +881,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cin; d.CP = l.d.cp; d.mtiles = l.d.mtiles_p; d.transposed = 1;
         }
         if (nd > 0) {
-            WUNET_LAUNCH(pack_weights_kernel, dim3(128, nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_LAUNCH(pack_weights_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
             WUNET_CHECK_LAUNCH();
         }
         if (c->h3) {
@@ -890,7 +897,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
             }
             if (n3 > 0) {
-                WUNET_LAUNCH(pack_h3_kernel, dim3(128, n3), dim3(WUNET_THREADS), 0, st, t3);
+                WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), n3), dim3(WUNET_THREADS), 0, st, t3);
                 WUNET_CHECK_LAUNCH();
             }
         }
