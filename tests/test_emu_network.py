@@ -123,6 +123,13 @@ def test_fp16_split_four_rows_per_wave(emu_engine_h3, monkeypatch):
     test_fp16_split_train_step_matches_oracle(emu_engine_h3, 2, 32, 2, 1024, "mse")
 
 
+def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
+    """wgrad_h3_reduce_serial_kernel (one thread per float4 of dW walks the splits; the planner uses it for the deep levels
+    of the 12-level net: <= 64 splits of >= 8192 float4) forced onto every layer of a small net."""
+    monkeypatch.setenv("WUNET_REDUCE_SERIAL", "100000,0")
+    test_fp16_split_train_step_matches_oracle(emu_engine_h3, 3, 16, 3, 1024, "mse")
+
+
 def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3):
     """wunet_backward_range in three buckets == one wunet_backward, bit for bit, with the split kernels forced on (per-layer
     gradient scales and split weight packs have to survive the bucket boundaries) - the path GradSync drives."""

@@ -51,6 +51,52 @@ struct WgradH3ReduceArgs {
     int Cout, Cin, taps, mrep, tw, nblocks, mblocks, cib;
 };
 
+// dW [Cout][Cin][TAPS] <- the four rows of tile-major float4 i = ((((bm*nblocks + bn)*4 + wave)*mrep + mt)*tw + t)*64 + lane
+__device__ __forceinline__ void wgrad_h3_scatter(const WgradH3ReduceArgs& A, size_t i, const double* u)
+{
+    size_t j = i;
+    const int lane = (int)(j & 63); j >>= 6;
+    const int t = (int)(j % A.tw); j /= A.tw;
+    const int mt = (int)(j % A.mrep); j /= A.mrep;
+    const int wave = (int)(j & 3); j >>= 2;
+    const int bn = (int)(j % A.nblocks), bm = (int)(j / A.nblocks);
+    const int grp = A.taps == 15 ? wave >> 1 : wave, t0 = A.taps == 15 ? (wave & 1) * 8 : 0;
+    const int ci = bn * A.cib + grp * 16 + (lane & 15), tap = t0 + t;
+    const int co = (bm * A.mrep + mt) * 16 + (lane >> 4) * 4;
+    if (ci < A.Cin && tap < A.taps) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co + r < A.Cout) A.dw[((size_t)(co + r) * A.Cin + ci) * A.taps + tap] = (float)u[r];
+    }
+}
+
+// Few splits and many outputs (the deep levels: 9-64 splits of a 0.1-3 MB dW): one thread per float4 walks the splits itself -
+// coalesced 16-byte loads, eight in flight, no LDS, no barrier.  (The 16-split-lane form below spends these layers waiting
+// on two barriers per 16 outputs: 29 us for 33 MB at the 32-sample level.)  fp32 in groups of 8 consecutive splits, fp64
+// across, fixed order.
+__global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_serial_kernel(WgradH3ReduceArgs A)
+{
+    const size_t n4 = (size_t)A.mblocks * A.nblocks * WUNET_WAVES * A.mrep * A.tw * 64;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
+        double u[4] = {0.0, 0.0, 0.0, 0.0};
+        int r = 0;
+        for (; r + 8 <= A.splits; r += 8) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const wunet_f4 v = wunet_ld4(A.part + (size_t)(r + k) * A.part_stride + 4 * i);
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            }
+            u[0] += (double)a0; u[1] += (double)a1; u[2] += (double)a2; u[3] += (double)a3;
+        }
+        for (; r < A.splits; ++r) {
+            const wunet_f4 v = wunet_ld4(A.part + (size_t)r * A.part_stride + 4 * i);
+            u[0] += (double)v[0]; u[1] += (double)v[1]; u[2] += (double)v[2]; u[3] += (double)v[3];
+        }
+        wgrad_h3_scatter(A, i, u);
+    }
+}
+
 __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3ReduceArgs A)
 {
     __shared__ double red[16][16][4];
@@ -82,21 +128,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3R
             double u[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int k = 0; k < 16; ++k) { u[0] += red[k][og][0]; u[1] += red[k][og][1]; u[2] += red[k][og][2]; u[3] += red[k][og][3]; }
-            // decode the tile-major index: i = ((((bm*nblocks + bn)*4 + wave)*mrep + mt)*tw + t)*64 + lane
-            size_t j = i;
-            const int lane = (int)(j & 63); j >>= 6;
-            const int t = (int)(j % A.tw); j /= A.tw;
-            const int mt = (int)(j % A.mrep); j /= A.mrep;
-            const int wave = (int)(j & 3); j >>= 2;
-            const int bn = (int)(j % A.nblocks), bm = (int)(j / A.nblocks);
-            const int grp = A.taps == 15 ? wave >> 1 : wave, t0 = A.taps == 15 ? (wave & 1) * 8 : 0;
-            const int ci = bn * A.cib + grp * 16 + (lane & 15), tap = t0 + t;
-            const int co = (bm * A.mrep + mt) * 16 + (lane >> 4) * 4;
-            if (ci < A.Cin && tap < A.taps) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (co + r < A.Cout) A.dw[((size_t)(co + r) * A.Cin + ci) * A.taps + tap] = (float)u[r];
-            }
+            wgrad_h3_scatter(A, i, u);
         }
     }
 }
