@@ -162,38 +162,58 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc[0] = s; sc[1] = inv; }
+    // One thread computes 8 channels x 4 consecutive samples (16-byte loads of g and z).  Its four 16-byte pieces per array
+    // would leave every store instruction of a wave 16-byte pieces at a 64-byte stride (measured on the operand passes and
+    // here: partial-line scattered stores cost 1.3 % of the step in this kernel alone), so the wave's 4 KiB of hi and of lo
+    // are turned in LDS: lane l then stores pieces l, 64+l, 128+l, 192+l - 1 KiB contiguous per instruction.  The output
+    // address of thread i is linear in i (piece 4*i + j), whatever the row boundaries.
+    __shared__ wunet_h8 tb[2][WUNET_THREADS * 4];
     const int l4n = L >> 2;
     const size_t total = (size_t)B * C8 * l4n;
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
-        const int l4 = (int)(i & (size_t)(l4n - 1));
-        const size_t row = i >> (logL - 2);
-        const int b = (int)(row / (size_t)C8), c8 = (int)(row - (size_t)b * C8);
-        wunet_f4 v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c8 * 8 + e;
-            const bool ok = c < C;
-            const size_t o = ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4;
-            const wunet_f4 gv = wunet_ld4(g + o), zv = wunet_ld4(z + o);
-            const float a = k1[ok ? c : 0], bb = k2[ok ? c : 0], d = k3[ok ? c : 0];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[e][j] = ok ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;
-        }
-        wunet_half* ph = hi + (row * L + 4 * (size_t)l4) * 8;
-        wunet_half* pl = lo + (row * L + 4 * (size_t)l4) * 8;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wunet_h8 h, l;
+    const int lane = (int)(threadIdx.x & 63), wbase = (int)(threadIdx.x & ~63u);
+    for (size_t base = (size_t)blockIdx.x * WUNET_THREADS; base < total; base += (size_t)gridDim.x * WUNET_THREADS) {
+        const size_t i = base + threadIdx.x;
+        if (i < total) {
+            const int l4 = (int)(i & (size_t)(l4n - 1));
+            const size_t row = i >> (logL - 2);
+            const int b = (int)(row / (size_t)C8), c8 = (int)(row - (size_t)b * C8);
+            wunet_f4 v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                wunet_half x, y;
-                wunet_split_h(v[e][j], x, y);
-                wunet_put_half(h, e, x);
-                wunet_put_half(l, e, y);
+                const int c = c8 * 8 + e;
+                const bool ok = c < C;
+                const size_t o = ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4;
+                const wunet_f4 gv = wunet_ld4(g + o), zv = wunet_ld4(z + o);
+                const float a = k1[ok ? c : 0], bb = k2[ok ? c : 0], d = k3[ok ? c : 0];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[e][j] = ok ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;
             }
-            wunet_sth8(ph + 8 * j, h);
-            wunet_sth8(pl + 8 * j, l);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                wunet_h8 h, l;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    wunet_half x, y;
+                    wunet_split_h(v[e][j], x, y);
+                    wunet_put_half(h, e, x);
+                    wunet_put_half(l, e, y);
+                }
+                tb[0][threadIdx.x * 4 + j] = h;
+                tb[1][threadIdx.x * 4 + j] = l;
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = 64 * j + lane;                               // of this wave's 256
+            const size_t src = base + wbase + (piece >> 2);                // the thread that produced it
+            if (src < total) {
+                const size_t o = (4 * (base + wbase) + piece) * 8;
+                wunet_sth8(hi + o, tb[0][wbase * 4 + piece]);
+                wunet_sth8(lo + o, tb[1][wbase * 4 + piece]);
+            }
+        }
+        __syncthreads();
     }
 }
 
