@@ -922,6 +922,14 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL;
         const dim3 ga(l.cout, l.a_split);
         const bool tiny = l.L < 4;
+        // a whole channel in one pass of one block (the levels of <= 16 samples at batch 64): BatchNorm-backward finalize and
+        // g_z inside pass A - two launches of ~5 us (latency, not bandwidth) less per such level
+        const bool fuse = !tiny && i < NL - 1 && !(i > 0 && l.h3d) && l.a_split == 1 && (size_t)c->B * l.L <= 4 * WUNET_THREADS &&
+                          !getenv("WUNET_NO_PASSA_FUSE");
+        if (fuse) {
+            p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
+            p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.L;
+        }
         if (i == NL - 1) {
             p.g0 = ws + c->gh_off; p.g1 = params[4 * NL]; p.hpart = ws + c->hpart2_off;
             WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);      // (the last layer has T >= 4 samples)
@@ -933,45 +941,49 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             p.g0 = ws + nx.dx; p.Cg0 = nx.cin;
             p.up_scale = (float)(l.L - 1) / (float)(2 * l.L - 1);
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_UP, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
         } else {
             const LayerPlan& dc = c->ly[2 * n - i];
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + dc.dx; p.Cg0 = dc.cin; p.coff = dc.c0; p.g1 = ws + nx.dx;
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_ENC, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
         }
         WUNET_CHECK_LAUNCH();
-        BnBwdArgs b{};
-        b.part = ws + c->bpart_off; b.rows = l.a_split; b.gamma = params[4 * i + 2]; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
-        b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
-        b.C = l.cout; b.count = (double)c->B * l.L;
-        b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
-        WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
-        WUNET_CHECK_LAUNCH();
-
-        // ---- g_z = k1*g + k2*z + k3, materialised once for both gradient GEMMs (fp32 in place, or scaled hi/lo halves)
-        {
-            const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
-            size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
-            if (blocks > 8192) blocks = 8192;
-            if (i > 0 && l.h3d) {
-                const int c8 = (l.cout + 7) / 8;
-                const size_t nt = (size_t)c->B * c8 * (l.L / 4);
-                size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
-                if (hb > 8192) hb = 8192;
-                WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                             (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
-                             ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                             c->B, l.cout, c8, l.L, l.logL);
-            } else if (tiny)
-                WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
-                             (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
-                             (size_t)c->B * l.cout * l.L, ws + l.g);
-            else
-                WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                             (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
+        if (!fuse) {
+            BnBwdArgs b{};
+            b.part = ws + c->bpart_off; b.rows = l.a_split; b.gamma = params[4 * i + 2]; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
+            b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
+            b.C = l.cout; b.count = (double)c->B * l.L;
+            b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
+            WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
             WUNET_CHECK_LAUNCH();
+
+            // ---- g_z = k1*g + k2*z + k3, materialised once for both gradient GEMMs (fp32 in place, or scaled hi/lo halves)
+            {
+                const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
+                size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
+                if (blocks > 8192) blocks = 8192;
+                if (i > 0 && l.h3d) {
+                    const int c8 = (l.cout + 7) / 8;
+                    const size_t nt = (size_t)c->B * c8 * (l.L / 4);
+                    size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
+                    if (hb > 8192) hb = 8192;
+                    WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                                 (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
+                                 ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
+                                 c->B, l.cout, c8, l.L, l.logL);
+                } else if (tiny)
+                    WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
+                                 (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
+                                 (size_t)c->B * l.cout * l.L, ws + l.g);
+                else
+                    WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                                 (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
+                WUNET_CHECK_LAUNCH();
+            }
         }
         // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
         //      + deterministic reduce

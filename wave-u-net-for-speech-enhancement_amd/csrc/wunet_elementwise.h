@@ -332,9 +332,12 @@ struct PassAArgs {
     int coff;            // ENC: channel offset of the skip part inside dXdec
     int B, C, L, logL;
     float up_scale;      // UP: (float)(L-1)/(2L-1)
+    // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
+    // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
+    const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
 };
 
-template <int MODE>
+template <int MODE, bool FUSE = false>
 __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
@@ -347,6 +350,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     float mg = 0.0f, mz = 0.0f;
+    wunet_f4 keep_g = wunet_f4{0.f, 0.f, 0.f, 0.f}, keep_z = keep_g;
+    size_t keep_i = 0;
+    bool have = false;
     for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += WUNET_THREADS) {
         const size_t p = q4 << 2;
         const int b = (int)(p >> A.logL), l = (int)(p & (size_t)(A.L - 1));
@@ -407,9 +413,30 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             mg = fmaxf(mg, fabsf(gv));
             mz = fmaxf(mz, fabsf(z[j] - mu));
         }
-        wunet_st4(A.gpre + zi, go);
+        if (FUSE) { keep_g = go; keep_z = z; keep_i = zi; have = true; }      // the thread's only iteration
+        else wunet_st4(A.gpre + zi, go);
     }
     block_sum2(s1, s2, red);
+    if (FUSE) {
+        // bn_finalize_bwd_kernel's arithmetic on the (float-rounded, as if through part[]) sums, then gz_materialize_kernel's
+        const double t1 = (double)(float)s1, t2 = (double)(float)s2;
+        const double m1 = t1 / A.count, m2 = t2 / A.count;
+        const double ar = (double)A.gamma[c] * (double)rstd;
+        const float k1 = (float)ar, k2 = (float)(-ar * m2 * (double)rstd), k3 = (float)(ar * m2 * (double)rstd * (double)mu - ar * m1);
+        if (threadIdx.x == 0) {
+            A.dgamma[c] = (float)t2;
+            A.dbeta[c] = (float)t1;
+            A.dbias[c] = 0.0f;
+            A.k1[c] = k1; A.k2[c] = k2; A.k3[c] = k3;
+        }
+        if (have) {
+            wunet_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = k1 * keep_g[j] + k2 * keep_z[j] + k3;
+            wunet_st4(A.gpre + keep_i, o);
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         float* pr = A.part + ((size_t)blockIdx.y * A.C + c) * 2;
         pr[0] = (float)s1;
