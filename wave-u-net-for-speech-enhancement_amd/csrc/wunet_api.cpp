@@ -940,6 +940,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + nx.dx; p.Cg0 = nx.cin;
             p.up_scale = (float)(l.L - 1) / (float)(2 * l.L - 1);
+            p.no_fast = getenv("WUNET_NO_PASSA_FAST") ? 1 : 0;
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_UP, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);

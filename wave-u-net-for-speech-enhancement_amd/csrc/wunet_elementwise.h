@@ -332,6 +332,7 @@ struct PassAArgs {
     int coff;            // ENC: channel offset of the skip part inside dXdec
     int B, C, L, logL;
     float up_scale;      // UP: (float)(L-1)/(2L-1)
+    int no_fast;         // UP: A/B switch, generic upsample^T walk for every thread
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
     const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
@@ -387,6 +388,28 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             }
             const float dlast = (j0 + 12 < Lo) ? row[j0 + 12] : 0.0f;
             g[0] = g[1] = g[2] = g[3] = 0.0f;
+            // interior threads: ATen's source pair of output j is ((j-1)>>1, +1) (checked against the exact coordinates), so
+            // input i receives, in ascending j, l1(2i-1) d[2i-1] + l1(2i) d[2i] + l0(2i+1) d[2i+1] + l0(2i+2) d[2i+2]: four
+            // multiply-adds instead of eleven rounds of compare-and-select (the pass is VALU-heavy: ~300 -> ~130 instructions)
+            bool fast = !A.no_fast && l >= 4 && l + 8 <= A.L;
+            float c0[10], c1[10];
+            if (fast) {
+#pragma unroll
+                for (int k = 3; k <= 12; ++k) {
+                    int i0, i1;
+                    wunet_up_coord(j0 + k, A.L, A.up_scale, i0, i1, c0[k - 3], c1[k - 3]);
+                    fast = fast && i0 == ((j0 + k - 1) >> 1) && i1 == i0 + 1;
+                }
+            }
+            if (fast) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    g[m] += c1[2 * m] * d[2 * m + 3];
+                    g[m] += c1[2 * m + 1] * d[2 * m + 4];
+                    g[m] += c0[2 * m + 2] * d[2 * m + 5];
+                    g[m] += c0[2 * m + 3] * (m == 3 ? dlast : d[m == 3 ? 0 : 2 * m + 6]);
+                }
+            } else
 #pragma unroll
             for (int k = 2; k <= 12; ++k) {                   // j = 2l-2 .. 2l+8
                 const int j = j0 + k;
