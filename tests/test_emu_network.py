@@ -130,6 +130,33 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
     test_fp16_split_train_step_matches_oracle(emu_engine_h3, 3, 16, 3, 1024, "mse")
 
 
+@pytest.mark.parametrize("switch,h3,cfg", [("WUNET_PREP4", 2, (4, 20, 3, 1024)),          # operand passes: 4 samples per thread
+                                           ("WUNET_NO_SKIP_FUSE", 2, (4, 16, 3, 1024)),   # decoder-side pass reads the skip itself
+                                           ("WUNET_NO_PASSA_FAST", 2, (4, 20, 3, 1024)),  # generic upsample-transpose walk
+                                           ("WUNET_NO_PASSA_FUSE", 0, (4, 12, 5, 128))])  # separate BN-backward finalize + g_z
+def test_measurement_switches_are_bit_identical(switch, h3, cfg, monkeypatch):
+    """The fused / re-mapped elementwise kernels of the default path compute exactly what the forms they replaced compute:
+    one training step with and without the A/B switch gives the same output and the same gradients, bit for bit."""
+    n, ci, B, T = cfg
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    results = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "1")
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=h3)
+        m, sd, pkg_loss = _build(n, ci, eng)
+        noisy, clean = plan.golden_batch(B, T, 0)
+        crit = pkg_loss.mse_loss()
+        crit._engine_override = eng
+        m.train()
+        out = m(torch.from_numpy(noisy))
+        crit(torch.from_numpy(clean), out).backward()
+        results.append([out.detach().numpy().copy()] + [p.grad.numpy().copy() for p in m.parameters()])
+    for a, b in zip(*results):
+        assert np.array_equal(a, b)
+
+
 def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3):
     """wunet_backward_range in three buckets == one wunet_backward, bit for bit, with the split kernels forced on (per-layer
     gradient scales and split weight packs have to survive the bucket boundaries) - the path GradSync drives."""

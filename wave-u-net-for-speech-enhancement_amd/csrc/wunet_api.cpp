@@ -749,7 +749,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 const size_t nt = (size_t)c->B * (ph.up_only ? ph.C0 / 8 : ph.C8) * (l.L / 4);
                 size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (hb > 16384) hb = 16384;
-                static const bool prep4 = getenv("WUNET_PREP4") != nullptr;               // A/B switch
+                const bool prep4 = getenv("WUNET_PREP4") != nullptr;                      // A/B switch (read per launch: tests toggle it)
                 if (prep4) {
                     WUNET_LAUNCH(prep4_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, ph);
                 } else {
