@@ -277,6 +277,7 @@ struct LayerPlan {
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
     int skip_from;                // decoder layer: > 0 = its skip half is written by the operand pass of encoder-side layer skip_from
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps, h3w_tp;   // weight gradient uses wgrad_h3_kernel
+    int feeds_h3;                 // the layer's activation is the (or a) source of a conv input that exists in the split layout
     size_t xh, xl;                // split activated input (float offsets)
     size_t gzh, gzl;              // split scaled g_z (float offsets)
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
@@ -293,6 +294,7 @@ struct wunet_ctx {
     int head_blocks;
     int h3 = 0;                   // fp16-split GEMMs: 0 off, 1 where the planner wants them, 2 wherever they can run
     size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_slot;   // float offsets
+    size_t fslot_off, wmax_off;   // forward segment: WUNET_SLOT_FLOATS per layer (x / weight scales, activation bound), partial max |W|
     size_t h3_wf_halfs, h3_wb_halfs;
     // side stream for the weight-gradient GEMMs (off the backward's critical chain), created lazily per device
     int side_dev = -1;
@@ -433,6 +435,15 @@ void layout_workspace(wunet_ctx* c)
     c->h3_wf_halfs = wfh;
     c->h3_wf_hi = off; off += align64((wfh + 1) / 2);
     c->h3_wf_lo = off; off += align64((wfh + 1) / 2);
+    c->fslot_off = off; off += align64((size_t)WUNET_SLOT_FLOATS * c->NL);
+    c->wmax_off = off; off += align64((size_t)WUNET_WMAX_PARTS * c->NL);
+    for (int i = 0; i < c->NL; ++i) c->ly[i].feeds_h3 = 0;
+    for (int i = 1; i < c->NL; ++i) {
+        const LayerPlan& l = c->ly[i];
+        if (!l.h3f) continue;
+        c->ly[l.src0].feeds_h3 = 1;
+        if (l.kind == LK_UPCAT) c->ly[l.src1].feeds_h3 = 1;
+    }
     c->fwd_floats = off;
 
     size_t wpkb = 0, bpart_max = 0, wgpart_max = 0;
@@ -509,24 +520,25 @@ void layout_workspace(wunet_ctx* c)
 }
 
 // ---- fp16-split helpers
-int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc, int B, int C, int L, hipStream_t st)
+int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc, const float* xb0, const float* xb1, float* xsc,
+                 int B, int C, int L, hipStream_t st)
 {
     const int c8 = (C + 7) / 8;
     const size_t n = (size_t)B * c8 * (L / 4);
     size_t blocks = (n + WUNET_THREADS - 1) / WUNET_THREADS;
     if (blocks > 16384) blocks = 16384;
-    WUNET_LAUNCH(split_act_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, hi, lo, sc, B, C, c8, L, ilog2(L));
+    WUNET_LAUNCH(split_act_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, hi, lo, sc, xb0, xb1, xsc, B, C, c8, L, ilog2(L));
     return 0;
 }
 
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
-                   const wunet_half* wl, const float* bias, const float* sc, float* out, float* stats, int B, int rows, int kch, int nch,
-                   int L, hipStream_t st)
+                   const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
+                   int kch, int nch, int L, hipStream_t st)
 {
     char pname[96];
     const double posn = (double)B * L;
     ConvH3Args a{};
-    a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.out = out; a.stats = stats;
+    a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.sc2 = sc2; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
     const int nseg = L >= 256 ? 1 : 256 / L, nstage = nch * (taps / 5);
     const int ksplit = (nstage + sps - 1) / sps;
@@ -544,7 +556,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
 }
 
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
-                    const float* sc, const float* zero, float* part, int B, hipStream_t st)
+                    const float* sc, const float* sc2, const float* zero, float* part, int B, hipStream_t st)
 {
     char pname[96];
     const double posn = (double)B * l.L;
@@ -557,7 +569,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     int rc;
     if (dma && nseg == 1 && tp == 128 && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
         WgradH3dArgs a{};
-        a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
+        a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
         a.zero = reinterpret_cast<const wunet_half*>(zero);
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
@@ -570,7 +582,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
         rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st);
     } else {
         WgradH3Args a{};
-        a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
+        a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
         snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
@@ -681,6 +693,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     // the encoder phase; measured on MI355X that is SLOWER (forward 4.24 vs 3.99 ms: the elementwise kernel steals
     // L2/HBM bandwidth and CU slots from the encoder GEMMs), so it stays on the caller's stream.
     hipStream_t sd = st;
+    float* const fslot = ws + c->fslot_off;
     // 1. pack all forward weights into MFMA-fragment order (one launch)
     {
         PackTable tab{};
@@ -698,6 +711,25 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         }
     }
     if (c->h3) {
+        // power-of-two scales of the split operands (wunet_h3_elem.h): partial max |W| of every layer with a split pack, and
+        // the activation bounds the x scales derive from (training: from gamma / beta; eval: cleared here, measured per layer)
+        {
+            ScaleTable T{};
+            bool any = false;
+            for (int i = 0; i < c->NL; ++i) {
+                const LayerPlan& l = c->ly[i];
+                ScaleDesc& d = T.d[i];
+                d.w = (l.h3f || l.h3d) ? params[4 * i] : nullptr; d.wn = (unsigned)((size_t)l.cout * l.cin * l.taps);
+                d.gamma = params[4 * i + 2]; d.beta = params[4 * i + 3]; d.C = l.cout;
+                d.sqrtn = sqrtf((float)((double)c->B * l.L));
+                any = any || l.h3f;
+            }
+            T.wmax = ws + c->wmax_off; T.slots = ws + c->fslot_off; T.training = training ? 1 : 0;
+            if (any) {
+                WUNET_LAUNCH(h3_scales_kernel, dim3(WUNET_WMAX_PARTS, c->NL), dim3(WUNET_THREADS), 0, st, T);
+                WUNET_CHECK_LAUNCH();
+            }
+        }
         PackH3Table tab{};
         int nd = 0;
         wunet_half* wh = reinterpret_cast<wunet_half*>(ws + c->h3_wf_hi);
@@ -708,6 +740,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             PackH3Desc& d = tab.d[nd++];
             d.w = params[4 * i]; d.hi = wh + l.h3f_wpk; d.lo = wl + l.h3f_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cout; d.kch = l.cin; d.mtiles = l.h3f_mtp; d.nch = l.h3f_nch; d.transposed = 0;
+            d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i; d.wsc = ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
         }
         if (nd > 0) {
             WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
@@ -732,13 +765,20 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 ph.xh = reinterpret_cast<wunet_half*>(ws + l.xh); ph.xl = reinterpret_cast<wunet_half*>(ws + l.xl);
                 ph.B = c->B; ph.C0 = l.c0; ph.C1 = l.cin - l.c0; ph.C8 = (l.cin + 7) / 8; ph.L = l.L; ph.logL = l.logL;
                 ph.kind = l.kind == LK_UPCAT ? 1 : 0;
-                ph.up_only = (l.kind == LK_UPCAT && l.skip_from > 0) ? 1 : 0;
-                if (l.kind == LK_DECIM) {
+                // the encoder-side pass can only write the decoder's skip half when the decoder's x scale is known that early:
+                // training mode (data-independent activation bounds); in eval mode the decoder-side pass reads the skip itself
+                ph.up_only = (l.kind == LK_UPCAT && l.skip_from > 0 && training) ? 1 : 0;
+                ph.xb0 = fslot + (size_t)WUNET_SLOT_FLOATS * l.src0 + 4;
+                ph.xb1 = l.kind == LK_UPCAT ? fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4 : nullptr;
+                ph.xsc = fslot + (size_t)WUNET_SLOT_FLOATS * i;
+                if (l.kind == LK_DECIM && training) {
                     const int dj = 2 * c->n - i + 1;             // the decoder layer that concatenates this pass's producer
                     if (dj < c->NL && c->ly[dj].skip_from == i) {
                         const LayerPlan& dl = c->ly[dj];
                         ph.sh = reinterpret_cast<wunet_half*>(ws + dl.xh); ph.sl = reinterpret_cast<wunet_half*>(ws + dl.xl);
                         ph.SC8 = (dl.cin + 7) / 8; ph.sc8off = dl.c0 / 8;
+                        ph.ssb0 = fslot + (size_t)WUNET_SLOT_FLOATS * dl.src0 + 4;
+                        ph.ssb1 = fslot + (size_t)WUNET_SLOT_FLOATS * dl.src1 + 4;
                     }
                 }
                 if (l.kind == LK_UPCAT) {
@@ -791,13 +831,15 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
             wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);
             wunet_half* xl = reinterpret_cast<wunet_half*>(ws + l.xl);
+            float* const sl = fslot + (size_t)WUNET_SLOT_FLOATS * i;      // [0..1] x scale, [2..3] weight scale
             if (!l.h3x) {
-                launch_split(xin, xh, xl, nullptr, c->B, l.cin, l.L, st);
+                launch_split(xin, xh, xl, nullptr, fslot + (size_t)WUNET_SLOT_FLOATS * l.src0 + 4,
+                             l.kind == LK_UPCAT ? fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4 : nullptr, sl, c->B, l.cin, l.L, st);
                 WUNET_CHECK_LAUNCH();
             }
             int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, l.h3f_sps, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
-                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], nullptr,
+                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
                                     l.cin, l.h3f_nch, l.L, st);
             if (rc) return rc;
@@ -837,6 +879,16 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
         WUNET_CHECK_LAUNCH();
+        if (!training && c->h3 && l.feeds_h3) {
+            // eval mode: the consumers' x scale comes from the measured maximum of |a z + s| (no batch statistics bound it)
+            const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
+            size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
+            if (blocks > 2048) blocks = 2048;
+            if (blocks < 1) blocks = 1;
+            WUNET_LAUNCH(act_max_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.z), (const float*)(ws + l.a),
+                         (const float*)(ws + l.s), l.cout, l.logL, n4, fslot + (size_t)WUNET_SLOT_FLOATS * i + 4);
+            WUNET_CHECK_LAUNCH();
+        }
     }
     // 3. head
     {
@@ -895,6 +947,8 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 PackH3Desc& d = t3.d[n3++];
                 d.w = params[4 * i]; d.hi = wh + l.h3d_wpk; d.lo = wl + l.h3d_wpk;
                 d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
+                d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i;      // the forward's maxima: the weights have not changed since
+                d.wsc = l.h3f ? nullptr : ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
             }
             if (n3 > 0) {
                 WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), n3), dim3(WUNET_THREADS), 0, st, t3);
@@ -1004,7 +1058,8 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
                 if (l.h3w)
                     rc = launch_wgrad_h3(l, reinterpret_cast<const wunet_half*>(ws + l.xh), reinterpret_cast<const wunet_half*>(ws + l.xl),
                                          reinterpret_cast<const wunet_half*>(ws + l.gzh), reinterpret_cast<const wunet_half*>(ws + l.gzl),
-                                         ws + c->h3_slot + 8 + 4 * i, ws + c->h3_slot, ws + c->wgpart_off, c->B, sd);
+                                         ws + c->h3_slot + 8 + 4 * i, ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i, ws + c->h3_slot,
+                                         ws + c->wgpart_off, c->B, sd);
                 else {
                     const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
                     rc = launch_wgrad_any(l.taps, w, l.w, sd);
@@ -1050,6 +1105,7 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp, l.h3d_sps, gh, gl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
+                                    ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2,
                                     split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();

@@ -101,6 +101,22 @@ __device__ __forceinline__ void wunet_split_h(float x, wunet_half& hi, wunet_hal
     lo = wunet_f2h(x - wunet_h2f(hi));
 }
 
+// Power-of-two scale 2^k with 2^k * bound in [2^T, 2^(T+1)) - multiplying by it is exact, so the split operands keep their 22 bits
+// whatever the magnitude of the tensor (the conv -> BatchNorm pair makes the weight scale a free gauge, gamma / beta set the
+// activations').  bound = 0 / inf / nan: scale 1.  fp16 tops out at 65504 < 2^16: T = 13 leaves a factor 4 above the bound.
+#define WUNET_SCALE_T 13
+__device__ __forceinline__ void wunet_pow2_scale(float bound, float& s, float& inv)
+{
+    s = 1.0f; inv = 1.0f;
+    const unsigned u = wunet_fbits(bound) & 0x7fffffffu;
+    if (u >= 0x00800000u && u < 0x7f800000u) {
+        int k = WUNET_SCALE_T - ((int)(u >> 23) - 127);
+        k = k > 100 ? 100 : (k < -100 ? -100 : k);
+        s = ldexpf(1.0f, k);
+        inv = ldexpf(1.0f, -k);
+    }
+}
+
 #define WUNET_THREADS 256
 #define WUNET_WAVES 4
 #define WUNET_SLOPE 0.1f

@@ -26,6 +26,7 @@ struct ConvH3Args {
     const wunet_half* wh; const wunet_half* wl;   // packed
     const float* bias;                            // [Cout] or nullptr
     const float* sc;                              // nullptr or {scale, 1/scale} of the input: the result is multiplied by sc[1]
+    const float* sc2;                             // nullptr or {scale, 1/scale} of the packed weights: ... and by sc2[1]
     float* out;                                   // [B][Cout][L] fp32
     float* stats;                                 // nullptr or [Cout][ntiles][2]: sum, sum of squares per 256-position tile
     int B, Cout, C8, NCH, L, logL;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
 
     // ---- epilogue (as conv_mfma_kernel): un-scale, bias, store, BN statistics of the bias-free conv
     //      (a K split stores its bias-free partial sum; statistics then come from the reduce kernel)
-    const float inv = A.sc ? A.sc[1] : 1.0f;
+    const float inv = A.sc ? A.sc[1] : 1.0f, inv2 = A.sc2 ? A.sc2[1] : 1.0f;     // powers of two: exact (applied one after the other: their product may leave fp32's range when the result does not)
     float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
     if (A.stats && !split) __syncthreads();       // the W tile's LDS is reused for the statistics hand-over
     const int bo = b + lseg;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
             wunet_f4 o;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const float v = acc[mt][nt][r] * inv;
+                const float v = acc[mt][nt][r] * inv * inv2;
                 s1[r] += v;
                 s2[r] += v * v;
                 o[nt] = v + bv;
@@ -256,6 +257,7 @@ struct WgradH3Args {
     const wunet_half* xh; const wunet_half* xl;   // [B][XC8][L][8]
     const wunet_half* gh; const wunet_half* gl;   // [B][GC8][L][8]  scaled g_z
     const float* sc;     // {scale, 1/scale} of g_z
+    const float* sc2;    // {scale, 1/scale} of x
     float* part;
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
     size_t part_stride;                           // floats between two splits' partial results
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
     // partial result, tile-major: [split][co block][ci block][wave][mt][tw][lane][4 rows] - every store is a contiguous
     // KiB per wave (the dW layout [co][ci][tap] would be 64 scattered dwords per store); wgrad_h3_reduce_kernel sums the
     // splits in this layout and scatters only the final dW
-    const float inv = A.sc[1];
+    const float inv = A.sc[1], inv2 = A.sc2[1];
     float* part = A.part + (size_t)blockIdx.x * A.part_stride
                 + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * WUNET_WAVES + wave) * (M_REP * TW)) * 256 + lane * 4;
 #pragma unroll
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
         for (int tw = 0; tw < TW; ++tw) {
             wunet_f4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[mt][tw][r] * inv;
+            for (int r = 0; r < 4; ++r) o[r] = acc[mt][tw][r] * inv * inv2;
             wunet_st4(part + (mt * TW + tw) * 256, o);
         }
 }
@@ -409,7 +411,8 @@ struct WgradH3dArgs {
     const wunet_half* xh; const wunet_half* xl;
     const wunet_half* gh; const wunet_half* gl;
     const wunet_half* zero;   // >= 16 zero bytes in global memory
-    const float* sc;
+    const float* sc;          // {scale, 1/scale} of g_z
+    const float* sc2;         // {scale, 1/scale} of x
     float* part;
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
     size_t part_stride;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(
     }
 #undef WUNET_WH3D_DMA
 
-    const float inv = A.sc[1];
+    const float inv = A.sc[1], inv2 = A.sc2[1];
     float* part = A.part + (size_t)blockIdx.x * A.part_stride
                 + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * WUNET_WAVES + wave) * (M_REP * TW)) * 256 + lane * 4;
 #pragma unroll
@@ -541,7 +544,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(
         for (int tw = 0; tw < TW; ++tw) {
             wunet_f4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = acc[mt][tw][r] * inv;
+            for (int r = 0; r < 4; ++r) o[r] = acc[mt][tw][r] * inv * inv2;
             wunet_st4(part + (mt * TW + tw) * 256, o);
         }
 }

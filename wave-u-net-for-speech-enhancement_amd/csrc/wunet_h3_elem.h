@@ -4,13 +4,104 @@
 #include "wunet_elementwise.h"
 #include "wunet_h3.h"
 
+// ---------------------------------------------------------------------------- power-of-two scales of the split operands
+// Per-layer scale slots in the forward segment of the workspace, 8 floats per conv layer:
+//   [0],[1]  scale, 1/scale of the layer's conv INPUT x (written by the operand pass that produces x)
+//   [2],[3]  scale, 1/scale of the layer's weights (written by pack_h3_kernel from the partial maxima below)
+//   [4]      xb: an upper bound of |LeakyReLU(BN(z))| of the layer's OUTPUT - what the consumers' x scales derive from.
+//            Training mode: max_c |gamma_c| sqrt(N) + |beta_c|, N = B*L positions (batch statistics: (z - mean)^2 <= N var, so
+//            |zhat| <= sqrt(N) - rigorous and data independent, known before the forward starts; measured values sit a factor
+//            sqrt(N)/6 below it, which costs nothing: the error floor of a split value is 2^-25 in scaled units against
+//            actual maxima of 2^5 or more).  Eval mode (running statistics, activations not normalised by the batch): the
+//            measured maximum of |a z + s|, act_max_kernel.
+#define WUNET_SLOT_FLOATS 8
+#define WUNET_WMAX_PARTS 32
+struct ScaleDesc {
+    const float* w; unsigned wn;                  // conv weight (nullptr: no split pack of this layer)
+    const float* gamma; const float* beta; int C; // BatchNorm affine parameters of the layer
+    float sqrtn;                                  // sqrt(B * L)
+};
+struct ScaleTable { ScaleDesc d[WUNET_MAX_CONV_LAYERS]; float* wmax; float* slots; int training; };
+
+// grid (WUNET_WMAX_PARTS, layers): partial max |W| per layer; block (0, layer) also writes the layer's xb (training) or clears
+// it (eval: act_max_kernel accumulates into it with atomicMax)
+__global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTable T)
+{
+    __shared__ float red[WUNET_THREADS];
+    const ScaleDesc& d = T.d[blockIdx.y];
+    const int tid = threadIdx.x;
+    if (d.w) {
+        float m = 0.0f;
+        for (unsigned i = blockIdx.x * WUNET_THREADS + tid; i < d.wn; i += gridDim.x * WUNET_THREADS) m = fmaxf(m, fabsf(d.w[i]));
+        red[tid] = m;
+        __syncthreads();
+        for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+            __syncthreads();
+        }
+        if (tid == 0) T.wmax[blockIdx.y * WUNET_WMAX_PARTS + blockIdx.x] = red[0];
+        __syncthreads();
+    }
+    if (blockIdx.x == 0) {
+        float m = 0.0f;
+        if (T.training)
+            for (int c = tid; c < d.C; c += WUNET_THREADS) m = fmaxf(m, fabsf(d.gamma[c]) * d.sqrtn + fabsf(d.beta[c]));
+        red[tid] = m;
+        __syncthreads();
+        for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
+            if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+            __syncthreads();
+        }
+        if (tid == 0) T.slots[blockIdx.y * WUNET_SLOT_FLOATS + 4] = red[0];
+    }
+}
+
+// eval mode: xb = max |a_c z + s_c| over the layer (>= |LeakyReLU(.)|), block maxima combined with atomicMax on the bit
+// pattern of the non-negative float (exact and order independent: deterministic)
+__global__ __launch_bounds__(WUNET_THREADS) void act_max_kernel(const float* z, const float* a, const float* s, int C, int logL,
+                                                                 size_t n4, float* xb)
+{
+    __shared__ float red[WUNET_THREADS];
+    float m = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
+        const int c = (int)((i >> (logL - 2)) % (size_t)C);
+        const float av = a[c], sv = s[c];
+        const wunet_f4 v = wunet_ld4(z + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) m = fmaxf(m, fabsf(av * v[j] + sv));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = WUNET_THREADS / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // NaN / inf maxima saturate to the largest finite float: the scale stays defined (the data is garbage either way)
+        const unsigned u = wunet_fbits(red[0]) & 0x7fffffffu;
+        atomicMax(reinterpret_cast<unsigned*>(xb), u < 0x7f800000u ? u : 0x7f7fffffu);
+    }
+}
+
+// x scale of a conv input whose sources' activation bounds are xb0 (and xb1): every thread derives the same value
+__device__ __forceinline__ void wunet_x_scale(const float* xb0, const float* xb1, float& s, float& inv)
+{
+    wunet_pow2_scale(fmaxf(xb0[0], xb1 ? xb1[0] : 0.0f), s, inv);
+}
+
 // fp32 [B][C][L]  ->  hi / lo [B][C8][L][8] halfs of sc[0]*x (sc == nullptr: unscaled).  One thread per
 // (channel group, 4 samples): 8 float4 loads, 4+4 16-byte stores.
 __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x, wunet_half* hi, wunet_half* lo, const float* sc,
+                                                                   const float* xb0, const float* xb1, float* xsc,
                                                                    int B, int C, int C8, int L, int logL)
 {
     const int l4n = L >> 2;
-    const float s = sc ? sc[0] : 1.0f;
+    float s = sc ? sc[0] : 1.0f;
+    if (xb0) {                                  // scale from the sources' activation bounds; block 0 publishes it for the GEMMs
+        float inv;
+        wunet_x_scale(xb0, xb1, s, inv);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { xsc[0] = s; xsc[1] = inv; }
+    }
     const size_t total = (size_t)B * C8 * l4n;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int l4 = (int)(i & (size_t)(l4n - 1));
@@ -231,6 +322,11 @@ struct PrepH3Args {
     // decoder input that concatenates it (unet_basic.py:95) - into that layer's split arrays at channel group sc8off
     wunet_half* sh; wunet_half* sl; int SC8, sc8off;
     int up_only;         // kind 1: the skip half was written by the encoder-side pass: only the C0/8 upsampled groups
+    // power-of-two scale of the split values: derived from the activation bounds of the sources (slot [4] of their layers),
+    // published as {scale, 1/scale} in xsc by block 0; ssb0 / ssb1: the sources of the decoder layer whose skip half this pass
+    // writes (its own pass derives and publishes the same scale)
+    const float* xb0; const float* xb1; float* xsc;
+    const float* ssb0; const float* ssb1;
 };
 
 // One thread = 8 channels of ONE sample, consecutive lanes = consecutive samples: every store instruction of a wave
@@ -248,6 +344,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
     const int Lh = A.L >> 1, C = A.C0 + A.C1;
     const int ngrp = UP_ONLY ? A.C0 / 8 : A.C8;              // channel groups this launch produces
     const size_t total = (size_t)A.B * ngrp * A.L;
+    float xs_ = 1.0f, xinv_ = 1.0f, ss_ = 1.0f;
+    wunet_x_scale(A.xb0, A.xb1, xs_, xinv_);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { A.xsc[0] = xs_; A.xsc[1] = xinv_; }
+    if (SKIP_DST) { float si_; wunet_x_scale(A.ssb0, A.ssb1, ss_, si_); }
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int p = (int)(i & (size_t)(A.L - 1));
         const unsigned grow = (unsigned)(i >> A.logL);
@@ -275,7 +375,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                     }
                 }
                 wunet_half a, d;
-                wunet_split_h(v, a, d);
+                wunet_split_h(xs_ * v, a, d);
                 wunet_put_half(h, e, a);
                 wunet_put_half(l, e, d);
             }
@@ -299,7 +399,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                     const int c = c8 * 8 + e;
                     const float v = c < C ? wunet_lrelu(A.a0[c] * A.z0[((size_t)b * A.C0 + c) * (size_t)(2 * A.L) + q] + A.s0[c]) : 0.0f;
                     wunet_half a, d;
-                    wunet_split_h(v, a, d);
+                    wunet_split_h(ss_ * v, a, d);
                     wunet_put_half(h, e, a);
                     wunet_put_half(l, e, d);
                 }
@@ -316,6 +416,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
     const int l4n = A.L >> 2, Lh = A.L >> 1, C = A.C0 + A.C1;
     const int ngrp = A.up_only ? A.C0 / 8 : A.C8;            // channel groups this launch produces
     const size_t total = (size_t)A.B * ngrp * l4n;
+    float xs_ = 1.0f, xinv_ = 1.0f, ss_ = 1.0f;
+    wunet_x_scale(A.xb0, A.xb1, xs_, xinv_);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { A.xsc[0] = xs_; A.xsc[1] = xinv_; }
+    if (A.kind == 0 && A.sh) { float si_; wunet_x_scale(A.ssb0, A.ssb1, ss_, si_); }
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int l4 = (int)(i & (size_t)(l4n - 1));
         const size_t grow = i >> (A.logL - 2);
@@ -383,7 +487,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 wunet_half a, d;
-                wunet_split_h(v[e][j], a, d);
+                wunet_split_h(xs_ * v[e][j], a, d);
                 wunet_put_half(h, e, a);
                 wunet_put_half(l, e, d);
             }
@@ -401,7 +505,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     wunet_half a, d;
-                    wunet_split_h((j & 1) ? vo[e][j >> 1] : v[e][j >> 1], a, d);
+                    wunet_split_h(ss_ * ((j & 1) ? vo[e][j >> 1] : v[e][j >> 1]), a, d);
                     wunet_put_half(h, e, a);
                     wunet_put_half(l, e, d);
                 }
@@ -423,6 +527,8 @@ struct PackH3Desc {
     int rows, kch;         // GEMM rows / K channels (Cout,Cin forward; Cin,Cout transposed)
     int mtiles, nch;       // padded m-tiles, chunks of 32 K channels
     int transposed;
+    const float* wmax;     // WUNET_WMAX_PARTS partial maxima of |w| (h3_scales_kernel)
+    float* wsc;            // {scale, 1/scale} of the packed weights, published by block 0 (nullptr: another pack of this layer did)
 };
 struct PackH3Table { PackH3Desc d[WUNET_MAX_CONV_LAYERS]; };
 
@@ -430,6 +536,21 @@ __global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
 {
     const PackH3Desc& d = tab.d[blockIdx.y];
     const int total = d.mtiles * d.nch * d.taps * 512;
+    // the layer's weight scale: max |w| -> [2^13, 2^14); every block derives the same value from the partial maxima
+    __shared__ float wsc_sh[2];
+    if (threadIdx.x < 64) {
+        float m = threadIdx.x < WUNET_WMAX_PARTS ? d.wmax[threadIdx.x] : 0.0f;
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, wunet_shfl_xor(m, k));
+        if (threadIdx.x == 0) {
+            float s_, i_;
+            wunet_pow2_scale(m, s_, i_);
+            wsc_sh[0] = s_; wsc_sh[1] = i_;
+            if (blockIdx.x == 0 && d.wsc) { d.wsc[0] = s_; d.wsc[1] = i_; }
+        }
+    }
+    __syncthreads();
+    const float wscale = wsc_sh[0];
     for (int idx = blockIdx.x * WUNET_THREADS + threadIdx.x; idx < total; idx += gridDim.x * WUNET_THREADS) {
         const int e = idx & 7, i = (idx >> 3) & 15, q = (idx >> 7) & 3;
         int r = idx >> 9;
@@ -440,7 +561,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
         if (row < d.rows && k < d.kch)
             v = d.transposed ? d.w[((size_t)k * d.Cin + row) * d.taps + (d.taps - 1 - t)] : d.w[((size_t)row * d.Cin + k) * d.taps + t];
         wunet_half a, b;
-        wunet_split_h(v, a, b);
+        wunet_split_h(wscale * v, a, b);
         d.hi[idx] = a;
         d.lo[idx] = b;
     }
