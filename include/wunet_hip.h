@@ -118,6 +118,16 @@ int wunet_op_conv1d_dgrad(const float* gz, const float* w, float* dx,
 int wunet_op_conv1d_wgrad(const float* gz, const float* x, float* dw,
                           int B, int Cin, int Cout, int L, int K, void* stream);
 
+/* The same three ops on the fp16-split kernels (conv_h3_kernel / wgrad_h3d_kernel / wgrad_h3_kernel of csrc/wunet_h3.h) with
+ * the planner's tiling for the geometry and device-derived power-of-two operand scales: L >= 16, B*L >= 256, and Cin >= 16
+ * for the two gradients (the network planner's own conditions).  They allocate scratch and synchronise. */
+int wunet_op_conv1d_split(const float* x, const float* w, const float* bias, float* z,
+                          int B, int Cin, int Cout, int L, int K, void* stream);
+int wunet_op_conv1d_dgrad_split(const float* gz, const float* w, float* dx,
+                                int B, int Cin, int Cout, int L, int K, void* stream);
+int wunet_op_conv1d_wgrad_split(const float* gz, const float* x, float* dw,
+                                int B, int Cin, int Cout, int L, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

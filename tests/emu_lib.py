@@ -54,3 +54,27 @@ def op_wgrad(gz, x, K):
     dw = np.full((Cout, Cin, K), np.nan, np.float32)
     check(lib().wunet_op_conv1d_wgrad(fp(gz), fp(x), fp(dw), B, Cin, Cout, L, K, None))
     return dw
+
+
+def op_conv1d_split(x, w, bias):
+    B, Cin, L = x.shape
+    Cout, _, K = w.shape
+    z = np.full((B, Cout, L), np.nan, np.float32)
+    check(lib().wunet_op_conv1d_split(fp(x), fp(w), fp(bias), fp(z), B, Cin, Cout, L, K, None))
+    return z
+
+
+def op_dgrad_split(gz, w, Cin):
+    B, Cout, L = gz.shape
+    K = w.shape[2]
+    dx = np.full((B, Cin, L), np.nan, np.float32)
+    check(lib().wunet_op_conv1d_dgrad_split(fp(gz), fp(w), fp(dx), B, Cin, Cout, L, K, None))
+    return dx
+
+
+def op_wgrad_split(gz, x, K):
+    B, Cout, L = gz.shape
+    Cin = x.shape[1]
+    dw = np.full((Cout, Cin, K), np.nan, np.float32)
+    check(lib().wunet_op_conv1d_wgrad_split(fp(gz), fp(x), fp(dw), B, Cin, Cout, L, K, None))
+    return dw

@@ -201,7 +201,7 @@ def test_full_size_properties(pkg, dev):
         ref = tsd[k].grad
         err = (p.grad.cpu() - ref).abs().max().item()
         rel = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
-        assert err < TOL and rel < 2e-2, (k, err, rel)
+        assert err < TOL and rel < 1e-3, (k, err, rel)        # measured: ~1e-5
     post = m.state_dict()
     for k in plan.buffer_names(n, ci):
         if "num_batches" in k:
@@ -399,5 +399,171 @@ def test_gemm_paths_match_reference(pkg, dev, mode, n, ci, B, T):
         # nets average thousands of them out and keep the flat 1e-4 bar.
         small = B * T < 16 * 16384
         bar = max(TOL, 5e-2 * ref.abs().max().item()) if small else TOL
-        assert err < bar and rel < (6e-2 if small else 2e-2), (k, err, rel)
+        assert err < bar and rel < (6e-2 if small else 1e-3), (k, err, rel)
     print(f"gemm path mode={mode} n={n} B={B} T={T}: out err {(out.detach().cpu() - o2.detach()).abs().max().item():.2e}, worst grad err {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# single-op parity of the fp16-split kernels at every BASELINE layer geometry (SURVEY.md section 8a per-layer table, B = 64)
+def _baseline_split_layers():
+    out = []
+    for i, (prefix, c_in, c_out, k) in enumerate(plan.conv_layers(12, 24)):
+        L = 16384 >> (i if i <= 12 else 24 - i)
+        if L >= 16 and c_in >= 16:
+            out.append(pytest.param(prefix, c_in, c_out, k, L, id=f"{prefix}-{c_in}x{c_out}-L{L}"))
+    return out
+
+
+def _profiled_kernels(lib, fn):
+    lib.wunet_profile_enable(1)
+    try:
+        fn()
+        buf = ctypes.create_string_buffer(1 << 14)
+        lib.wunet_profile_collect(buf, len(buf))
+    finally:
+        lib.wunet_profile_enable(0)
+    return [ln.split("\t")[0] for ln in buf.value.decode().strip().splitlines()]
+
+
+@pytest.mark.parametrize("prefix,Cin,Cout,K,L", _baseline_split_layers())
+def test_split_ops_at_baseline_geometries(engine, dev, prefix, Cin, Cout, K, L):
+    """conv_h3_kernel (forward conv and data gradient), wgrad_h3d_kernel / wgrad_h3_kernel (weight gradient) through
+    wunet_op_*_split with the planner's tiling for the geometry, batch 64, against F.conv1d and its autograd in float64 on the
+    host (the reference's op, model/unet_basic.py:10,23, at twice the precision).  Conv and data gradient are checked on three
+    batch items (frames are independent: the other 61 only cost host time), the weight gradient - a sum over all frames - in
+    full.  Measured errors are ~1e-6 of the tensor norm (22-bit operands, fp32 accumulation); the bars are 1e-5."""
+    import torch.nn.functional as F
+    B = 64
+    g = torch.Generator().manual_seed(L * 7 + Cin)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / float(np.sqrt(Cin * K))
+    b = torch.randn(Cout, generator=g)
+    gz = torch.randn(B, Cout, L, generator=g)
+    xd, wd, bd, gd = x.to(dev), w.to(dev), b.to(dev), gz.to(dev)
+    z = torch.full((B, Cout, L), float("nan"), device=dev)
+    dx = torch.full((B, Cin, L), float("nan"), device=dev)
+    dw = torch.full((Cout, Cin, K), float("nan"), device=dev)
+    lib = engine.lib
+
+    def run():
+        assert lib.wunet_op_conv1d_split(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), z.data_ptr(), B, Cin, Cout, L, K, None) == 0, lib.wunet_last_error()
+        assert lib.wunet_op_conv1d_dgrad_split(gd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, Cin, Cout, L, K, None) == 0, lib.wunet_last_error()
+        assert lib.wunet_op_conv1d_wgrad_split(gd.data_ptr(), xd.data_ptr(), dw.data_ptr(), B, Cin, Cout, L, K, None) == 0, lib.wunet_last_error()
+    names = _profiled_kernels(lib, run)
+    torch.cuda.synchronize()
+    assert sum(nm.startswith("conv_h3_kernel<%d," % K) for nm in names) >= 1, names
+    wg = [nm for nm in names if nm.startswith("wgrad_h3")]
+    assert len(wg) == 1 and wg[0].startswith(("wgrad_h3d_kernel<%d," if L >= 128 else "wgrad_h3_kernel<%d,") % K), names
+
+    items = [0, 17, B - 1]
+    x64, w64, gz64 = x.double(), w.double(), gz.double()
+    zr = F.conv1d(x64[items], w64, b.double(), padding=K // 2)
+    dxr = torch.nn.grad.conv1d_input((len(items), Cin, L), w64, gz64[items], padding=K // 2)
+    dwr = torch.nn.grad.conv1d_weight(x64, (Cout, Cin, K), gz64, padding=K // 2)
+
+    def check(got, ref, what):
+        got = got.cpu().double()
+        rel = ((got - ref).norm() / ref.norm()).item()
+        err = ((got - ref).abs().max() / ref.abs().max()).item()
+        assert rel < 1e-5 and err < 1e-5, (what, rel, err)
+    check(z[items], zr, "conv")
+    check(dx[items], dxr, "dgrad")
+    check(dw, dwr, "wgrad")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the split path must not depend on the gauge of the checkpoint (conv -> BatchNorm: model/unet_basic.py:9-14, 22-27)
+def _rescaled(n, ci, wscale=1.0, gscale=1.0):
+    sd = plan.golden_state(n, ci, 0)
+    for prefix, _, _, _ in plan.conv_layers(n, ci):
+        for key, sc in ((".0.weight", wscale), (".0.bias", wscale), (".1.weight", gscale), (".1.bias", gscale)):
+            sd[prefix + key] = (sd[prefix + key] * np.float32(sc)).astype(np.float32)
+    return sd
+
+
+def _step_with_state(pkg, dev, sd, n, ci, noisy, clean, h3):
+    eng = importlib.import_module(PKG_NAME + ".engine").Engine(h3=h3)
+    m = pkg.Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+    m.to(dev).train()
+    m._engine_override = eng
+    crit = pkg.mse_loss()
+    crit._engine_override = eng
+    out = m(_t(noisy, dev))
+    crit(_t(clean, dev), out).backward()
+    torch.cuda.synchronize()
+    return out.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in m.named_parameters()}
+
+
+def _errs(out, grads, ref_out, ref_grads):
+    oe = float(np.abs(out - ref_out).max())
+    ge = 0.0
+    for k, gr in grads.items():
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            continue
+        r = ref_grads[k]
+        ge = max(ge, float(np.linalg.norm((gr - r).ravel()) / max(np.linalg.norm(r.ravel()), 1e-30)))
+    return oe, ge
+
+
+@pytest.mark.parametrize("case", [dict(wscale=1e-3), dict(wscale=1e-2), dict(wscale=0.05), dict(wscale=1e2), dict(wscale=1e4),
+                                  dict(gscale=0.05), dict(gscale=20.0), dict(wscale=1e-3, gscale=20.0)],
+                         ids=lambda c: ",".join(f"{k}={v}" for k, v in c.items()))
+@pytest.mark.parametrize("net", [(3, 16, 3, 1024), (2, 24, 2, 1024)], ids=["n3ci16", "n2ci24"])
+def test_split_path_is_scale_invariant_on_hardware(pkg, dev, net, case):
+    """tests/test_scale_robustness.py on the GPU: the split kernels forced onto every level of two small nets whose conv
+    weights / BatchNorm affine parameters are re-scaled, against the f64 oracle and against the fp32 MFMA path."""
+    n, ci, B, T = net
+    sd = _rescaled(n, ci, **case)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, True, "mse", precision="f64")
+    o3, g3 = _step_with_state(pkg, dev, sd, n, ci, noisy, clean, 2)
+    o0, g0 = _step_with_state(pkg, dev, sd, n, ci, noisy, clean, 0)
+    oe3, ge3 = _errs(o3, g3, ref["out"], ref["grads"])
+    oe0, ge0 = _errs(o0, g0, ref["out"], ref["grads"])
+    assert np.isfinite(o3).all()
+    assert oe3 <= max(1e-5, 3 * oe0) and ge3 <= max(1e-4, 3 * ge0), (oe3, ge3, oe0, ge0)
+    assert oe3 <= 3 * oe0 + 2e-6 and ge3 <= 3 * ge0 + 2e-6, (oe3, ge3, oe0, ge0)
+
+
+@pytest.mark.parametrize("case", [dict(wscale=1e-2), dict(wscale=1e4), dict(gscale=0.05), dict(gscale=20.0)],
+                         ids=lambda c: ",".join(f"{k}={v}" for k, v in c.items()))
+def test_default_path_is_scale_invariant_at_12_levels(pkg, dev, case):
+    """The 12-level / 16384-sample net, batch 8, default planner (split kernels on the levels >= 32 samples) on re-scaled
+    checkpoints against the reference's ATen CPU path: the bars of test_gemm_paths_match_reference hold at every scale (the
+    gamma x 20 case puts 20x larger values in front of the tanh, so its output bar is relative to the fp32 MFMA path)."""
+    n, ci, B, T = 12, 24, 8, 16384
+    sd = _rescaled(n, ci, **case)
+    noisy, clean = plan.golden_batch(B, T, 5)
+    tsd = torch_port.state_to_torch(sd, requires_grad=True)
+    o2 = torch_port.forward(tsd, torch.from_numpy(noisy), n, ci, True)
+    torch_port.loss_value("mse", torch.from_numpy(clean), o2).backward()
+    ref_out = o2.detach().numpy()
+    ref_grads = {k: v.grad.numpy() for k, v in tsd.items() if v.requires_grad}
+    o1, g1 = _step_with_state(pkg, dev, sd, n, ci, noisy, clean, 1)
+    o0, g0 = _step_with_state(pkg, dev, sd, n, ci, noisy, clean, 0)
+    oe1, ge1 = _errs(o1, g1, ref_out, ref_grads)
+    oe0, ge0 = _errs(o0, g0, ref_out, ref_grads)
+    print(f"12-level {case}: split out {oe1:.2e} grad {ge1:.2e} | fp32 out {oe0:.2e} grad {ge0:.2e}")
+    assert np.isfinite(o1).all()
+    assert oe1 <= max(2e-5, 3 * oe0) and ge1 <= max(1e-3, 3 * ge0), (oe1, ge1, oe0, ge0)
+
+
+def test_eval_forward_on_rescaled_checkpoint(pkg, dev):
+    """Eval mode (enhancement.py:66) with running statistics that do not describe the data: the activation scale of the split
+    operands comes from the measured maxima (act_max_kernel), so nothing overflows fp16 and the output keeps the 1e-5 bar."""
+    n, ci, B, T = 3, 16, 2, 1024
+    sd = _rescaled(n, ci, wscale=300.0)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, False, "mse", precision="f64")
+    outs = []
+    for h3 in (2, 0):
+        eng = importlib.import_module(PKG_NAME + ".engine").Engine(h3=h3)
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        m.to(dev).eval()
+        m._engine_override = eng
+        with torch.no_grad():
+            outs.append(m(_t(noisy, dev)).cpu().numpy())
+    e3, e0 = np.abs(outs[0] - ref["out"]).max(), np.abs(outs[1] - ref["out"]).max()
+    assert np.isfinite(outs[0]).all() and e3 <= 1e-5 and e3 <= 3 * e0 + 2e-6, (e3, e0)

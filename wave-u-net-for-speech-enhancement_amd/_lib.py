@@ -14,7 +14,7 @@ EXPORTS = [
     "wunet_backward", "wunet_backward_range", "wunet_loss_scratch_bytes", "wunet_loss_forward",
     "wunet_loss_backward", "wunet_layer_info", "wunet_num_conv_layers", "wunet_op_conv1d",
     "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
-    "wunet_adam_step", "wunet_set_h3",
+    "wunet_adam_step", "wunet_set_h3", "wunet_op_conv1d_split", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split",
 ]
 
 _vp = ctypes.c_void_p
@@ -40,10 +40,10 @@ def declare(lib):
     lib.wunet_loss_backward.argtypes = [_i, _vp, _vp, _vp, _sz, _vp, _vp]
     lib.wunet_layer_info.argtypes = [_vp, _i, ctypes.POINTER(_sz), ctypes.POINTER(_i), ctypes.POINTER(_i)]
     lib.wunet_num_conv_layers.argtypes = [_vp]
-    for name in ("wunet_op_conv1d",):
+    for name in ("wunet_op_conv1d", "wunet_op_conv1d_split"):
         getattr(lib, name).argtypes = [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
-    lib.wunet_op_conv1d_dgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
-    lib.wunet_op_conv1d_wgrad.argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
+    for name in ("wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split"):
+        getattr(lib, name).argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_adam_step.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_longlong, _vp]
     lib.wunet_set_h3.argtypes = [_vp, _i]

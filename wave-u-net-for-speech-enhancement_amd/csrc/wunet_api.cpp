@@ -350,6 +350,56 @@ int h3_stages_per_split(int blocks, int nstage)
     return (nstage + ks - 1) / ks;
 }
 
+// Tiling of conv_h3_kernel for one GEMM (rows x B*L positions, K = kch channels x taps): accumulator rows per wave, padded
+// m-tiles, chunks of 32 K channels, K stages per split and the split count.  Shared by the network planner and the
+// single-op entry points, so a geometry gets the same kernel instantiation either way.
+struct H3ConvPlan { int mrep, mtp, nch, sps, ksplit, ntiles; };
+
+H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* order_env)
+{
+    H3ConvPlan p{};
+    const long long posn = (long long)B * L;
+    p.ntiles = (int)((posn + 255) / 256);
+    const int ntg = taps / 5, c8 = (kch + 7) / 8, mt = (rows + 15) / 16;
+    // (4 accumulator rows per wave only exist un-segmented: L >= 256)
+    p.mrep = pick_mrep_h3(mt, L >= 256 ? order_env : nullptr, h3_order(taps, L, p.ntiles, mt));
+    p.mtp = round_up(mt, p.mrep);
+    p.nch = (c8 + 3) / 4;
+    p.sps = h3_stages_per_split(p.ntiles * (p.mtp / p.mrep), p.nch * ntg);
+    p.ksplit = (p.nch * ntg + p.sps - 1) / p.sps;
+    return p;
+}
+
+// Tiling of the split weight gradient of one layer (fills l.h3w_*)
+void plan_h3_wgrad(LayerPlan& l, int B)
+{
+    const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
+    // 3 or 2 m-tiles per block: those DMA-staged kernels fit two blocks per CU, and two independent blocks beat taller
+    // single blocks (weight gradients 1.25 -> 1.14 ms per step; the register-staged kernel preferred 5-6 m-tiles)
+    // per-layer sweep (profiles/r1_h3_rows_per_wave_sweep.txt): 4 where 5 taps divide evenly at >= 256 samples
+    // (decoder.7: 79 -> 68 us); 2 on the short 15-tap levels (encoder.6/7/9: 44 -> 39, 32 -> 29, 21 -> 18 us)
+    const char* w_order = (l.taps == 5 && l.L >= 256 && mt % 4 == 0) ? "432" : (l.taps == 15 && l.L <= 256) ? "2" : "32";
+    l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", w_order);
+    l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
+    l.h3w_nblocks = (l.cin + cib - 1) / cib;
+    // positions per K chunk.  256 doubles the time a chunk's prefetch has to land and is 5-8 % faster for the kernel
+    // alone (one block per CU, it waits on its staging), but with its 87 KB of LDS only one conv_h3 block fits
+    // beside it and the whole step (weight gradients run concurrently with the data-gradient chain) is slower:
+    // 6.76 vs 6.68 ms.  128 unless WUNET_H3W_TP=256.
+    static const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;
+    l.h3w_tp = tp_env == 256 ? 256 : 128;
+    // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 up to 3
+    const bool sb2 = !getenv("WUNET_NO_H3W_SB") && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && l.h3w_tp == 128 &&
+                     ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
+    const long long slots = 256LL * ((l.h3w_mrep <= 2 || sb2) ? 2 : 1);      // resident blocks: launch bounds of the wgrad kernels
+    long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
+    if (ks < 1) ks = 1;
+    const long long chunks = ((long long)B * l.L + l.h3w_tp - 1) / l.h3w_tp;
+    if (ks > chunks) ks = chunks;
+    l.h3w_cps = (int)((chunks + ks - 1) / ks);
+    l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
+}
+
 void layout_workspace(wunet_ctx* c)
 {
     const int B = c->B, T = c->T, ci = c->ci;
@@ -376,19 +426,16 @@ void layout_workspace(wunet_ctx* c)
             l.h3d = (big && i > 0 && l.cin >= 16 && (c->h3 == 2 || l.L < 256 || (l.d.nrep == 4 && l.d.ksplit == 1))) ? 1 : 0;
             l.h3w = l.h3d;
             l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
-            const int ntiles = (int)((posn + 255) / 256), ntg = l.taps / 5;
-            if (l.h3f) {                               // (4 accumulator rows per wave only exist un-segmented: L >= 256)
-                const int c8 = (l.cin + 7) / 8, mt = (l.cout + 15) / 16;
-                l.h3f_mrep = pick_mrep_h3(mt, l.L >= 256 ? "WUNET_H3_ORDER" : nullptr, h3_order(l.taps, l.L, ntiles, mt)); l.h3f_mtp = round_up(mt, l.h3f_mrep); l.h3f_nch = (c8 + 3) / 4;
-                l.h3f_sps = h3_stages_per_split(ntiles * (l.h3f_mtp / l.h3f_mrep), l.h3f_nch * ntg);
-                l.f.ksplit = (l.h3f_nch * ntg + l.h3f_sps - 1) / l.h3f_sps;
-                l.f.grid_x = ntiles;                   // one statistics row per tile (f_rows below)
+            if (l.h3f) {
+                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cout, l.cin, l.taps, "WUNET_H3_ORDER");
+                l.h3f_mrep = p.mrep; l.h3f_mtp = p.mtp; l.h3f_nch = p.nch; l.h3f_sps = p.sps;
+                l.f.ksplit = p.ksplit;
+                l.f.grid_x = p.ntiles;                 // one statistics row per tile (f_rows below)
             }
             if (l.h3d) {
-                const int c8 = (l.cout + 7) / 8, mt = (l.cin + 15) / 16;
-                l.h3d_mrep = pick_mrep_h3(mt, l.L >= 256 ? "WUNET_H3D_ORDER" : nullptr, h3_order(l.taps, l.L, ntiles, mt)); l.h3d_mtp = round_up(mt, l.h3d_mrep); l.h3d_nch = (c8 + 3) / 4;
-                l.h3d_sps = h3_stages_per_split(ntiles * (l.h3d_mtp / l.h3d_mrep), l.h3d_nch * ntg);
-                l.d.ksplit = (l.h3d_nch * ntg + l.h3d_sps - 1) / l.h3d_sps;
+                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cin, l.cout, l.taps, "WUNET_H3D_ORDER");
+                l.h3d_mrep = p.mrep; l.h3d_mtp = p.mtp; l.h3d_nch = p.nch; l.h3d_sps = p.sps;
+                l.d.ksplit = p.ksplit;
             }
             if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
         }
@@ -456,33 +503,7 @@ void layout_workspace(wunet_ctx* c)
         l.k3 = off; off += align64(l.cout);
         l.d_wpk = wpkb;
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
-        if (l.h3w) {
-            const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
-            // 3 or 2 m-tiles per block: those DMA-staged kernels fit two blocks per CU, and two independent blocks beat taller
-            // single blocks (weight gradients 1.25 -> 1.14 ms per step; the register-staged kernel preferred 5-6 m-tiles)
-            // per-layer sweep (profiles/r1_h3_rows_per_wave_sweep.txt): 4 where 5 taps divide evenly at >= 256 samples
-            // (decoder.7: 79 -> 68 us); 2 on the short 15-tap levels (encoder.6/7/9: 44 -> 39, 32 -> 29, 21 -> 18 us)
-            const char* w_order = (l.taps == 5 && l.L >= 256 && mt % 4 == 0) ? "432" : (l.taps == 15 && l.L <= 256) ? "2" : "32";
-            l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", w_order);
-            l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
-            l.h3w_nblocks = (l.cin + cib - 1) / cib;
-            // positions per K chunk.  256 doubles the time a chunk's prefetch has to land and is 5-8 % faster for the kernel
-            // alone (one block per CU, it waits on its staging), but with its 87 KB of LDS only one conv_h3 block fits
-            // beside it and the whole step (weight gradients run concurrently with the data-gradient chain) is slower:
-            // 6.76 vs 6.68 ms.  128 unless WUNET_H3W_TP=256.
-            static const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;
-            l.h3w_tp = tp_env == 256 ? 256 : 128;
-            // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 up to 3
-            const bool sb2 = !getenv("WUNET_NO_H3W_SB") && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && l.h3w_tp == 128 &&
-                             ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
-            const long long slots = 256LL * ((l.h3w_mrep <= 2 || sb2) ? 2 : 1);      // resident blocks: launch bounds of the wgrad kernels
-            long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
-            if (ks < 1) ks = 1;
-            const long long chunks = ((long long)B * l.L + l.h3w_tp - 1) / l.h3w_tp;
-            if (ks > chunks) ks = chunks;
-            l.h3w_cps = (int)((chunks + ks - 1) / ks);
-            l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
-        }
+        if (l.h3w) plan_h3_wgrad(l, B);
         const size_t wg = l.h3w ? (size_t)l.h3w_ksplit * h3w_part_stride(l) : (size_t)l.w.rows * l.cout * l.cin * l.taps;
         if (wg > wgpart_max) wgpart_max = wg;
         long long sp = ((long long)B * l.L) / 4096;
@@ -1316,6 +1337,129 @@ int wunet_op_conv1d_wgrad(const float* gz, const float* x, float* dw, int B, int
     }
     hipStreamSynchronize(st);
     hipFree(part);
+    if (rc) return rc;
+    WUNET_CHECK_LAUNCH();
+    return WUNET_OK;
+}
+
+// ---- single-op entry points of the fp16-split kernels: the same planner, operand passes and GEMM kernels the network
+//      uses for that geometry (scales from the measured maxima, as in eval mode)
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;            // (a kernel-launch lambda must capture the raw pointer, never the owner)
+    bool alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess; }
+    float* f() const { return (float*)p; }
+    wunet_half* h() const { return (wunet_half*)p; }
+};
+
+int op_split_check(int B, int Cin, int Cout, int L, int K, bool backward)
+{
+    if (op_check(B, Cin, Cout, L, K)) return WUNET_E_ARG;
+    if (L < 16 || (long long)B * L < 256) return fail(WUNET_E_ARG, "the split kernels need L >= 16 and B*L >= 256");
+    if (backward && Cin < 16) return fail(WUNET_E_ARG, "the split data / weight gradient needs Cin >= 16");
+    return 0;
+}
+
+// fp32 [B][C][L] -> scaled hi / lo in the split layout; slot: 8 floats, [0..1] receive {scale, 1/scale}, [4] the measured max
+int op_split_operand(const float* x, int B, int C, int L, DevBuf& hi, DevBuf& lo, float* slot, const float* ones, const float* zeros, hipStream_t st)
+{
+    const int c8 = (C + 7) / 8;
+    if (!hi.alloc((size_t)B * c8 * L * 16) || !lo.alloc((size_t)B * c8 * L * 16)) return fail(WUNET_E_RUNTIME, "hipMalloc");
+    hipMemsetAsync(slot, 0, WUNET_SLOT_FLOATS * sizeof(float), st);
+    const size_t n4 = (size_t)B * C * L / 4;
+    size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
+    if (blocks > 2048) blocks = 2048;
+    WUNET_LAUNCH(act_max_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, ones, zeros, C, ilog2(L), n4, slot + 4);
+    return launch_split(x, hi.h(), lo.h(), nullptr, slot + 4, nullptr, slot, B, C, L, st);
+}
+
+int op_conv_split_common(const float* x, const float* w, const float* bias, float* out, int B, int kch, int rows, int Cout, int Cin,
+                         int L, int K, int transposed, hipStream_t st)
+{
+    const H3ConvPlan p = plan_h3_conv(B, L, rows, kch, K, transposed ? "WUNET_H3D_ORDER" : "WUNET_H3_ORDER");
+    DevBuf xh, xl, wh, wl, misc, part;
+    const size_t wh_halfs = (size_t)p.mtp * p.nch * K * 512, nout = (size_t)B * rows * L;
+    // misc: slot of x (8 floats) | slot of w (8) | partial weight maxima (32) | ones (kch) | zeros (kch)
+    if (!wh.alloc(wh_halfs * 2) || !wl.alloc(wh_halfs * 2) || !misc.alloc((48 + 2 * (size_t)kch) * sizeof(float)) ||
+        (p.ksplit > 1 && !part.alloc((size_t)p.ksplit * nout * sizeof(float))))
+        return fail(WUNET_E_RUNTIME, "hipMalloc");
+    float* xslot = misc.f(), *wslot = misc.f() + 8, *wmax = misc.f() + 16, *oz = misc.f() + 48;
+    WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz, (size_t)kch, 1.0f);
+    WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz + kch, (size_t)kch, 0.0f);
+    int rc = op_split_operand(x, B, kch, L, xh, xl, xslot, oz, oz + kch, st);
+    if (rc) return rc;
+    {
+        ScaleTable T{};
+        T.d[0].w = w; T.d[0].wn = (unsigned)((size_t)Cout * Cin * K); T.d[0].gamma = oz; T.d[0].beta = oz; T.d[0].C = 1; T.d[0].sqrtn = 0.0f;
+        T.wmax = wmax; T.slots = wslot; T.training = 0;          // (clears wslot[4], which nothing reads)
+        WUNET_LAUNCH(h3_scales_kernel, dim3(WUNET_WMAX_PARTS, 1), dim3(WUNET_THREADS), 0, st, T);
+        PackH3Table tab{};
+        PackH3Desc& d = tab.d[0];
+        d.w = w; d.hi = wh.h(); d.lo = wl.h(); d.Cout = Cout; d.Cin = Cin; d.taps = K; d.rows = rows; d.kch = kch; d.mtiles = p.mtp; d.nch = p.nch;
+        d.transposed = transposed; d.wmax = wmax; d.wsc = wslot + 2;
+        WUNET_LAUNCH(pack_h3_kernel, dim3(64, 1), dim3(WUNET_THREADS), 0, st, tab);
+    }
+    const bool split = p.ksplit > 1;
+    rc = launch_conv_h3(K, p.mrep, p.mtp, p.sps, xh.h(), xl.h(), wh.h(), wl.h(), split ? nullptr : bias, xslot, wslot + 2,
+                        split ? part.f() : out, nullptr, B, rows, kch, p.nch, L, st);
+    if (!rc && split) {
+        size_t blocks = (nout + WUNET_THREADS - 1) / WUNET_THREADS;
+        if (blocks > 2048) blocks = 2048;
+        const float* partp = part.f();
+        const int ks = p.ksplit;
+        WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, partp, ks, nout, out, bias, rows, ilog2(L));
+    }
+    hipStreamSynchronize(st);
+    if (rc) return rc;
+    WUNET_CHECK_LAUNCH();
+    return WUNET_OK;
+}
+}  // namespace
+
+int wunet_op_conv1d_split(const float* x, const float* w, const float* bias, float* z, int B, int Cin, int Cout, int L, int K, void* stream)
+{
+    if (op_split_check(B, Cin, Cout, L, K, false)) return WUNET_E_ARG;
+    return op_conv_split_common(x, w, bias, z, B, Cin, Cout, Cout, Cin, L, K, 0, (hipStream_t)stream);
+}
+
+int wunet_op_conv1d_dgrad_split(const float* gz, const float* w, float* dx, int B, int Cin, int Cout, int L, int K, void* stream)
+{
+    if (op_split_check(B, Cin, Cout, L, K, true)) return WUNET_E_ARG;
+    return op_conv_split_common(gz, w, nullptr, dx, B, Cout, Cin, Cout, Cin, L, K, 1, (hipStream_t)stream);
+}
+
+int wunet_op_conv1d_wgrad_split(const float* gz, const float* x, float* dw, int B, int Cin, int Cout, int L, int K, void* stream)
+{
+    if (op_split_check(B, Cin, Cout, L, K, true)) return WUNET_E_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    LayerPlan l{};
+    l.cin = Cin; l.cout = Cout; l.taps = K; l.L = L; l.logL = ilog2(L);
+    plan_h3_wgrad(l, B);
+    DevBuf xh, xl, gh, gl, misc, part;
+    const int cmax = Cin > Cout ? Cin : Cout;
+    // misc: 8 zero floats (DMA zero page) | slot of g_z | slot of x | ones | zeros
+    if (!misc.alloc((24 + 2 * (size_t)cmax) * sizeof(float)) || !part.alloc((size_t)l.h3w_ksplit * h3w_part_stride(l) * sizeof(float)))
+        return fail(WUNET_E_RUNTIME, "hipMalloc");
+    float* zero = misc.f(), *gslot = misc.f() + 8, *xslot = misc.f() + 16, *oz = misc.f() + 24;
+    hipMemsetAsync(zero, 0, 8 * sizeof(float), st);
+    WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz, (size_t)cmax, 1.0f);
+    WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz + cmax, (size_t)cmax, 0.0f);
+    int rc = op_split_operand(gz, B, Cout, L, gh, gl, gslot, oz, oz + cmax, st);
+    if (!rc) rc = op_split_operand(x, B, Cin, L, xh, xl, xslot, oz, oz + cmax, st);
+    if (!rc) rc = launch_wgrad_h3(l, xh.h(), xl.h(), gh.h(), gl.h(), gslot, xslot, zero, part.f(), B, st);
+    if (!rc) {
+        WgradH3ReduceArgs ra{};
+        ra.part = part.f(); ra.part_stride = h3w_part_stride(l); ra.splits = l.h3w_ksplit; ra.dw = dw;
+        ra.Cout = Cout; ra.Cin = Cin; ra.taps = K; ra.mrep = l.h3w_mrep; ra.tw = K == 15 ? 8 : 5;
+        ra.nblocks = l.h3w_nblocks; ra.mblocks = l.h3w_mblocks; ra.cib = K == 15 ? 32 : 64;
+        size_t blocks = (ra.part_stride / 4 + 15) / 16;
+        if (blocks > 4096) blocks = 4096;
+        WUNET_LAUNCH(wgrad_h3_reduce_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, ra);
+    }
+    hipStreamSynchronize(st);
     if (rc) return rc;
     WUNET_CHECK_LAUNCH();
     return WUNET_OK;
