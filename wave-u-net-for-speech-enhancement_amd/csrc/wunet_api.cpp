@@ -554,13 +554,14 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
 
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
-                   int kch, int nch, int L, hipStream_t st)
+                   int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr)
 {
     char pname[96];
     const double posn = (double)B * L;
     ConvH3Args a{};
     a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.sc2 = sc2; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
+    a.ev_a = ev_a; a.ev_s = ev_s; a.xrows = xrows;
     const int nseg = L >= 256 ? 1 : 256 / L, nstage = nch * (taps / 5);
     const int ksplit = (nstage + sps - 1) / sps;
     a.stages_per_split = sps; a.split_stride = (size_t)B * rows * L;
@@ -845,9 +846,28 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         // 2b. conv (+ bias, + per-wave BN statistics partials) on the matrix cores
         const bool tiny = l.L < 4;
         const bool split = l.f.ksplit > 1 || tiny;      // both leave a bias-free result in the split buffer
+        // BatchNorm statistics -> scale/shift for the consumers (+ running stats); eval mode: from the running statistics
+        BnFwdArgs b{};
+        b.stats = ws + c->stats_off; b.rows = l.f_rows; b.bias = params[4 * i + 1];
+        b.gamma = params[4 * i + 2]; b.beta = params[4 * i + 3];
+        b.running_mean = running[2 * i]; b.running_var = running[2 * i + 1]; b.nbt = nbt[i];
+        b.a = ws + l.a; b.s = ws + l.s; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
+        b.C = l.cout; b.count = (double)c->B * l.L; b.training = training ? 1 : 0;
+        // eval mode, a layer whose activation feeds split operands: its consumers' operand scale comes from the measured maximum
+        // of |a z + s| (no batch statistics bound it).  The large producers (conv_first_kernel, un-split conv_h3_kernel) take it
+        // in their epilogue - the BatchNorm coefficients only depend on the running statistics, so they are finalised BEFORE the
+        // conv - the small ones get a pass of act_max_kernel over z.
+        const bool ev_need = !training && c->h3 && l.feeds_h3;
+        const bool ev_epi = ev_need && (l.first || (l.h3f && !split));
+        float* const xrows = ws + c->stats_off;         // (eval: the statistics rows are free)
+        if (ev_epi) {
+            WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
+            WUNET_CHECK_LAUNCH();
+        }
         if (l.first) {
             WUNET_LAUNCH(conv_first_kernel<15>, dim3((unsigned)l.f.grid_x), dim3(WUNET_THREADS), 0, st, xin, params[4 * i], params[4 * i + 1],
-                         ws + l.z, training ? ws + c->stats_off : (float*)nullptr, c->B, l.cout, l.L, l.logL);
+                         ws + l.z, training ? ws + c->stats_off : (float*)nullptr, c->B, l.cout, l.L, l.logL,
+                         ev_epi ? ws + l.a : (const float*)nullptr, ev_epi ? ws + l.s : (const float*)nullptr, ev_epi ? xrows : (float*)nullptr);
         } else if (l.h3f) {
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
             wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);
@@ -862,7 +882,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
-                                    l.cin, l.h3f_nch, l.L, st);
+                                    l.cin, l.h3f_nch, l.L, st, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr);
             if (rc) return rc;
         } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;
@@ -877,13 +897,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         }
         WUNET_CHECK_LAUNCH();
         // 2c. BatchNorm statistics -> scale/shift for the consumers (+ running stats)
-        BnFwdArgs b{};
-        b.stats = ws + c->stats_off; b.rows = l.f_rows; b.bias = params[4 * i + 1];
-        b.gamma = params[4 * i + 2]; b.beta = params[4 * i + 3];
-        b.running_mean = running[2 * i]; b.running_var = running[2 * i + 1]; b.nbt = nbt[i];
-        b.a = ws + l.a; b.s = ws + l.s; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
-        b.C = l.cout; b.count = (double)c->B * l.L; b.training = training ? 1 : 0;
-        if (split) {
+        if (ev_epi) {
+            const int nrows = l.first ? l.f.grid_x : (int)(((long long)c->B * l.L + 255) / 256) * (l.h3f_mtp / l.h3f_mrep);
+            WUNET_LAUNCH(xb_reduce_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, (const float*)xrows, nrows, fslot + (size_t)WUNET_SLOT_FLOATS * i + 4);
+        } else if (split) {
             // sum the z-slices (+bias -> z) and reduce the BN statistics; short levels finish BN in the same launch
             const long long pos = (long long)c->B * l.L;
             int rs = (int)(pos / 2048);
@@ -900,8 +917,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
         WUNET_CHECK_LAUNCH();
-        if (!training && c->h3 && l.feeds_h3) {
-            // eval mode: the consumers' x scale comes from the measured maximum of |a z + s| (no batch statistics bound it)
+        if (ev_need && !ev_epi) {
             const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
             if (blocks > 2048) blocks = 2048;
@@ -1382,11 +1398,11 @@ int op_conv_split_common(const float* x, const float* w, const float* bias, floa
     const H3ConvPlan p = plan_h3_conv(B, L, rows, kch, K, transposed ? "WUNET_H3D_ORDER" : "WUNET_H3_ORDER");
     DevBuf xh, xl, wh, wl, misc, part;
     const size_t wh_halfs = (size_t)p.mtp * p.nch * K * 512, nout = (size_t)B * rows * L;
-    // misc: slot of x (8 floats) | slot of w (8) | partial weight maxima (32) | ones (kch) | zeros (kch)
-    if (!wh.alloc(wh_halfs * 2) || !wl.alloc(wh_halfs * 2) || !misc.alloc((48 + 2 * (size_t)kch) * sizeof(float)) ||
+    // misc: slot of x (8 floats) | slot of w (8) | partial weight maxima | ones (kch) | zeros (kch)
+    if (!wh.alloc(wh_halfs * 2) || !wl.alloc(wh_halfs * 2) || !misc.alloc((16 + WUNET_WMAX_PARTS + 2 * (size_t)kch) * sizeof(float)) ||
         (p.ksplit > 1 && !part.alloc((size_t)p.ksplit * nout * sizeof(float))))
         return fail(WUNET_E_RUNTIME, "hipMalloc");
-    float* xslot = misc.f(), *wslot = misc.f() + 8, *wmax = misc.f() + 16, *oz = misc.f() + 48;
+    float* xslot = misc.f(), *wslot = misc.f() + 8, *wmax = misc.f() + 16, *oz = misc.f() + 16 + WUNET_WMAX_PARTS;
     WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz, (size_t)kch, 1.0f);
     WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz + kch, (size_t)kch, 0.0f);
     int rc = op_split_operand(x, B, kch, L, xh, xl, xslot, oz, oz + kch, st);

@@ -586,9 +586,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float
 // x all Cout channels (the K+3 inputs sit in registers, the weights are wave-uniform scalar loads), one 16-byte
 // store per channel; BN statistics of the bias-free conv per (wave, channel) like the MFMA kernels
 // (stats [Cout][gridDim.x*4][2], one row per wave = 256 samples).  L >= 256: a wave lies inside one batch item.
+// Eval mode: ev_a / ev_s (this layer's BatchNorm scale / shift, known before the conv) and xrows [gridDim.x]: the block's
+// max |a z + s|, the activation bound the consumer's split-operand scale derives from.
 template <int K>
 __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* x, const float* w, const float* bias, float* out,
-                                                                    float* stats, int B, int Cout, int L, int logL)
+                                                                    float* stats, int B, int Cout, int L, int logL,
+                                                                    const float* ev_a, const float* ev_s, float* xrows)
 {
     constexpr int PAD = K / 2, NX = ((8 + 4 + PAD + 3) / 4) * 4;          // aligned window [l0 - 8, l0 + NX - 8)
     static_assert(PAD <= 8 && NX >= 8 + 4 + PAD, "window");
@@ -605,6 +608,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
         xv[4 * v] = t[0]; xv[4 * v + 1] = t[1]; xv[4 * v + 2] = t[2]; xv[4 * v + 3] = t[3];
     }
     const size_t rows = (size_t)gridDim.x * WUNET_WAVES, row = (size_t)blockIdx.x * WUNET_WAVES + wave;
+    float amax = 0.0f;
     for (int co = 0; co < Cout; ++co) {
         const float* wr = w + (size_t)co * K;
         wunet_f4 acc = wunet_f4{0.f, 0.f, 0.f, 0.f};
@@ -622,6 +626,11 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = acc[j] + bv;
             wunet_st4(out + ((size_t)b * Cout + co) * L + l0, o);
+            if (xrows) {
+                const float ea = ev_a[co], es = ev_s[co];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) amax = fmaxf(amax, fabsf(ea * o[j] + es));
+            }
         }
         if (stats) {
 #pragma unroll
@@ -635,6 +644,32 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
                 stp[1] = s2;
             }
         }
+    }
+    if (xrows) {
+        __shared__ float xm[WUNET_WAVES];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
+        if (lane == 0) xm[wave] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) xrows[blockIdx.x] = fmaxf(fmaxf(xm[0], xm[1]), fmaxf(xm[2], xm[3]));
+    }
+}
+
+// max over the per-block activation bounds of an eval-mode conv -> the layer's xb slot (one block)
+__global__ __launch_bounds__(WUNET_THREADS) void xb_reduce_kernel(const float* rows, int n, float* xb)
+{
+    __shared__ float red[WUNET_THREADS];
+    float m = 0.0f;
+    for (int i = threadIdx.x; i < n; i += WUNET_THREADS) m = fmaxf(m, fabsf(rows[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int st = WUNET_THREADS / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned u = wunet_fbits(red[0]) & 0x7fffffffu;           // NaN / inf saturate: the scale stays defined
+        xb[0] = u < 0x7f800000u ? red[0] : 3.0e38f;
     }
 }
 

@@ -29,6 +29,9 @@ struct ConvH3Args {
     const float* sc2;                             // nullptr or {scale, 1/scale} of the packed weights: ... and by sc2[1]
     float* out;                                   // [B][Cout][L] fp32
     float* stats;                                 // nullptr or [Cout][ntiles][2]: sum, sum of squares per 256-position tile
+    // eval mode (BatchNorm coefficients known before the conv): ev_a / ev_s = scale / shift of this layer's BatchNorm, xrows
+    // [gridDim.x] receives the block's max |a (v + bias) + s| - the activation bound the consumers' operand scale derives from
+    const float* ev_a; const float* ev_s; float* xrows;
     int B, Cout, C8, NCH, L, logL;
     int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
@@ -187,6 +190,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
     float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
     if (A.stats && !split) __syncthreads();       // the W tile's LDS is reused for the statistics hand-over
     const int bo = b + lseg;
+    float amax = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -203,7 +207,14 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
                 s2[r] += v * v;
                 o[nt] = v + bv;
             }
-            if (co < A.Cout && bo < A.B) wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
+            if (co < A.Cout && bo < A.B) {
+                wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
+                if (A.xrows) {
+                    const float ea = A.ev_a[co], es = A.ev_s[co];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
+                }
+            }
         }
         if (A.stats && !split) {
 #pragma unroll
@@ -220,6 +231,15 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
                 }
             }
         }
+    }
+    if (A.xrows) {                                // eval: block maximum of the activation bound (max is order independent)
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
+        __syncthreads();
+        float* rp = reinterpret_cast<float*>(ws);
+        if (lane == 0) rp[wave] = amax;
+        __syncthreads();
+        if (tid == 0) A.xrows[blockIdx.x] = fmaxf(fmaxf(rp[0], rp[1]), fmaxf(rp[2], rp[3]));
     }
     // one statistics row per block (256 positions): the four waves' sums are added in wave order
     if (A.stats && !split) {

@@ -15,7 +15,7 @@
 //            actual maxima of 2^5 or more).  Eval mode (running statistics, activations not normalised by the batch): the
 //            measured maximum of |a z + s|, act_max_kernel.
 #define WUNET_SLOT_FLOATS 8
-#define WUNET_WMAX_PARTS 32
+#define WUNET_WMAX_PARTS 64
 struct ScaleDesc {
     const float* w; unsigned wn;                  // conv weight (nullptr: no split pack of this layer)
     const float* gamma; const float* beta; int C; // BatchNorm affine parameters of the layer
