@@ -80,6 +80,15 @@ int wunet_backward(wunet_ctx* ctx, const float* noisy, const float* const* param
 int wunet_backward_range(wunet_ctx* ctx, const float* noisy, const float* const* params,
                          const float* enhanced, const float* grad_enhanced, void* workspace,
                          float* const* grads, int layer_begin, int layer_end, void* stream);
+/* wunet_backward_range without the final "caller's stream waits for the weight-gradient stream": the next range's
+ * data-gradient chain is not held up at the bucket boundary.  The weight gradients of the range are complete for a stream
+ * after wunet_backward_join(ctx, that_stream) - e.g. the stream the RCCL all-reduce of the bucket is enqueued from.  The range
+ * with layer_begin == 0 (the end of the backward) always joins `stream`.  The side stream is per (ctx, device): a ctx may be
+ * used from several devices / threads at once as long as each call runs with its device current. */
+int wunet_backward_range_async(wunet_ctx* ctx, const float* noisy, const float* const* params,
+                               const float* enhanced, const float* grad_enhanced, void* workspace,
+                               float* const* grads, int layer_begin, int layer_end, void* stream);
+int wunet_backward_join(wunet_ctx* ctx, void* stream);
 
 /* Replaces loss_function(clean, enhanced) (trainer/trainer.py:36; model/loss.py:3-7), mean reduction.
  * scratch: >= wunet_loss_scratch_bytes() device bytes.  loss_out: device float. */
@@ -92,10 +101,14 @@ int wunet_loss_backward(int kind, const float* clean, const float* enhanced, con
 
 /* replaces optimizer.step() of torch.optim.Adam(params, lr, betas) as the reference builds it
  * (train.py:31-35; eps, weight_decay=0, amsgrad=False fixed by the reference's call) for n_tensors tensors in one
- * or two launches.  step is the 1-based step count AFTER the increment (torch's state["step"]).  numels: host array. */
+ * or two launches.  step is the 1-based step count AFTER the increment (torch's state["step"]).  numels: host array.
+ * grad_scale multiplies every gradient first (1/world_size of the data-parallel average, trainer/base_trainer.py:26-27, folded
+ * into the step).  step_dev != NULL: the step count lives in device memory (int64), is incremented by the call and the bias
+ * corrections are computed on the device into hyper_dev (2 floats) - `step` is ignored; this is what makes the whole training
+ * step capturable in a hipGraph. */
 int wunet_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const size_t* numels, double lr, double beta1, double beta2, double eps,
-                    long long step, void* stream);
+                    long long step, double grad_scale, long long* step_dev, float* hyper_dev, void* stream);
 
 /* Introspection for tests / profiling: float offset of layer i's raw conv output inside the
  * workspace, its channel count and length. */

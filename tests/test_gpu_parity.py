@@ -579,3 +579,83 @@ def test_eval_forward_on_rescaled_checkpoint(pkg, dev):
             outs.append(m(_t(noisy, dev)).cpu().numpy())
     e3, e0 = np.abs(outs[0] - ref["out"]).max(), np.abs(outs[1] - ref["out"]).max()
     assert np.isfinite(outs[0]).all() and e3 <= 1e-5 and e3 <= 3 * e0 + 2e-6, (e3, e0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the trainer plugin on the GPU, eager and as one captured hipGraph per step
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipgraph"])
+def test_trainer_on_gpu_equals_the_written_out_loop(pkg, dev, tmp_path, graph):
+    """trainer.Trainer(...).train() against the reference's loop written out (trainer/trainer.py:30-38) with the same plugins:
+    identical parameters, buffers and optimiser state after 2 epochs x 4 steps - bit for bit, also when steps 4.. are replays of
+    ONE captured graph (forward + loss + backward + fused Adam with its device-side step counter; 3 eager warm-up steps)."""
+    trainer_mod = importlib.import_module(PKG_NAME + ".trainer")
+    dataset_mod = importlib.import_module(PKG_NAME + ".dataset")
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    n, ci, sl = 5, 8, 2048
+    ds = dataset_mod.Dataset(n_items=16, sample_length=sl, seed=2)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
+
+    def make():
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+        return m.to(dev), pkg.smooth_l1_loss(), None
+
+    cfg = {"root_dir": str(tmp_path), "experiment_name": "g", "trainer": {"epochs": 2, "save_checkpoint_interval": 0, "graph": graph}}
+    m1, crit1, _ = make()
+    opt1 = optim_mod.FusedAdam(m1.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    tr = trainer_mod.Trainer(cfg, False, m1, crit1, opt1, loader, None)
+    assert tr.use_graph == graph
+    tr.train()
+    assert (tr._graph is not None) == graph
+    m2, crit2, _ = make()
+    opt2 = optim_mod.FusedAdam(m2.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    m2.train()
+    losses = []
+    for _ in range(2):
+        tot = 0.0
+        for mix, cl, _ in loader:
+            opt2.zero_grad()
+            loss = crit2(cl.to(dev), m2(mix.to(dev)))
+            loss.backward()
+            opt2.step()
+            tot += loss.item()
+        losses.append(tot / len(loader))
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        s1, s2 = opt1.state[p1], opt2.state[p2]
+        assert int(s1["step"]) == int(s2["step"]) == 8
+        assert torch.equal(s1["exp_avg"], s2["exp_avg"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
+    assert np.allclose(tr.epoch_losses, losses, rtol=1e-5)
+
+
+def test_shard_loader_gathers_on_the_gpu(dev, tmp_path):
+    """waveform_dataset.ShardLoader with device=cuda - the shard is uploaded once (piecewise from the
+    memory map), every batch is one on-device gather of aligned windows; same draws as the host loader, bit for bit
+    (reference item contract: dataset/waveform_dataset.py:56-67, util/utils.py:101-113)."""
+    import wave
+    wd = importlib.import_module(PKG_NAME + ".waveform_dataset")
+    rng = np.random.default_rng(0)
+    lines = []
+    for i in range(7):
+        T = int(rng.integers(20000, 50000))
+        for tag in ("n", "c"):
+            x = (rng.random(T) * 1.8 - 0.9).astype(np.float32)
+            with wave.open(str(tmp_path / f"{tag}{i}.wav"), "wb") as w:
+                w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
+                w.writeframes((x * 32768).astype("<i2").tobytes())
+        lines.append(f"{tmp_path / f'n{i}.wav'} {tmp_path / f'c{i}.wav'}")
+    (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
+    prefix = str(tmp_path / "shard")
+    assert wd.pack_shard(str(tmp_path / "train.txt"), prefix) == 7
+    wd.ShardLoader.UPLOAD_CHUNK = 50000                      # several upload pieces even for this small corpus
+    gpu = wd.ShardLoader(prefix, batch_size=8, sample_length=16384, device=dev, seed=5, steps_per_epoch=3)
+    cpu = wd.ShardLoader(prefix, batch_size=8, sample_length=16384, device="cpu", seed=5, steps_per_epoch=3)
+    assert gpu.noisy.is_cuda and gpu.noisy.numel() == cpu.noisy.numel()
+    n = 0
+    for (mg, cg, ng), (mc, cc, nc) in zip(gpu, cpu):
+        assert mg.is_cuda and mg.shape == (8, 1, 16384) and mg.dtype == torch.float32 and mg.is_contiguous()
+        assert ng == nc and torch.equal(mg.cpu(), mc) and torch.equal(cg.cpu(), cc)
+        n += 1
+    assert n == 3

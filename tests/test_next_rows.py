@@ -1,5 +1,6 @@
 """CPU tests (emulator engine) of the SURVEY.md §8(f) rows built so far: f2 train-step driver, f3 chunked inference,
 and the synthetic dataset plugin."""
+import copy
 import importlib
 
 import numpy as np
@@ -93,3 +94,90 @@ def test_trainer_plugin_runs_the_hot_loop(emu_engine, tmp_path):
     assert tr3.start_epoch == 3
     for (k, a), (_, b) in zip(m1.named_parameters(), m3.named_parameters()):
         assert torch.equal(a, b), k
+
+
+def test_fused_adam_state_round_trips_with_torch_adam(emu_engine):
+    """The reference resumes with torch.optim.Adam.load_state_dict (trainer/base_trainer.py:74): FusedAdam's state_dict loads into
+    torch's Adam and steps there, torch's loads into FusedAdam; options the reference never sets are refused, not ignored."""
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+
+    def params():
+        torch.manual_seed(3)
+        return [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+
+    def grads(ps, k):
+        g = torch.Generator().manual_seed(10 + k)
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g)
+
+    pa, pb = params(), params()
+    fa = optim_mod.FusedAdam(pa, lr=2e-3, betas=(0.8, 0.99))
+    fa._engine_override = emu_engine
+    ta = torch.optim.Adam(pb, lr=2e-3, betas=(0.8, 0.99))
+    assert set(fa.param_groups[0]) == set(ta.param_groups[0])
+    for k in range(2):
+        grads(pa, k); grads(pb, k)
+        fa.step(); ta.step()
+    # FusedAdam -> torch.optim.Adam: load and keep stepping
+    pc = params()
+    tc = torch.optim.Adam(pc, lr=2e-3, betas=(0.8, 0.99))
+    tc.load_state_dict(copy.deepcopy(fa.state_dict()))       # (a checkpoint round trip copies; load_state_dict alone aliases the moments)
+    with torch.no_grad():
+        for p, q in zip(pc, pa):
+            p.copy_(q)
+    grads(pa, 2); grads(pb, 2); grads(pc, 2)
+    fa.step(); ta.step(); tc.step()
+    for a, b, c in zip(pa, pb, pc):
+        assert (a - b).abs().max() < 1e-6 and (a - c).abs().max() < 1e-6
+    # torch.optim.Adam -> FusedAdam
+    pd = params()
+    fd = optim_mod.FusedAdam(pd, lr=2e-3, betas=(0.8, 0.99))
+    fd._engine_override = emu_engine
+    fd.load_state_dict(copy.deepcopy(ta.state_dict()))
+    with torch.no_grad():
+        for p, q in zip(pd, pb):
+            p.copy_(q)
+    grads(pb, 3); grads(pd, 3)
+    ta.step(); fd.step()
+    for b, d in zip(pb, pd):
+        assert (b - d).abs().max() < 1e-6
+    bad = ta.state_dict()
+    bad["param_groups"][0]["weight_decay"] = 0.01
+    with pytest.raises(ValueError, match="weight_decay"):
+        fd.load_state_dict(bad)
+
+
+def test_fused_adam_device_step_counter_and_grad_scale(emu_engine):
+    """device_step=True (the hipGraph-capturable form: the step count and bias corrections live on the device) and grad_scale
+    (1/world folded into the step) give the numbers of the host-counted step on pre-scaled gradients."""
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    torch.manual_seed(4)
+    base = [torch.randn(33, 5), torch.randn(9)]
+    pa = [torch.nn.Parameter(t.clone()) for t in base]
+    pb = [torch.nn.Parameter(t.clone()) for t in base]
+    fa = optim_mod.FusedAdam(pa, lr=1e-2, device_step=True)
+    fb = optim_mod.FusedAdam(pb, lr=1e-2)
+    fa._engine_override = fb._engine_override = emu_engine
+    fa.grad_scale = 0.25
+    for k in range(4):
+        g = torch.Generator().manual_seed(k)
+        for a, b in zip(pa, pb):
+            a.grad = torch.randn(a.shape, generator=g)
+            b.grad = a.grad * 0.25
+        fa.step(); fb.step()
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    assert int(fa._dev[0][0]) == 4 and int(fa.state[pa[0]]["step"]) == 4
+
+
+def test_second_backward_and_input_gradient_are_refused_with_a_message(emu_engine):
+    m = _model(2, 4, emu_engine).train()
+    x = torch.zeros(2, 1, 64)
+    out = m(x)
+    out.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already run"):
+        out.sum().backward()
+    before = m.encoder[0].main[1].num_batches_tracked.clone()
+    with pytest.raises(NotImplementedError, match="waveform input"):
+        m(x.clone().requires_grad_(True))
+    assert torch.equal(m.encoder[0].main[1].num_batches_tracked, before)      # refused before the forward touched the buffers

@@ -104,3 +104,78 @@ def test_grad_sync_matches_average_of_shard_oracles(tmp_path):
             continue
         scale = max(np.abs(avg).max(), 1e-6)
         assert np.abs(got[k] - avg).max() < 3e-4 * scale + 1e-6, (k, np.abs(got[k] - avg).max(), scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole data-parallel training path through the trainer plugin: torchrun environment -> Trainer joins the process group,
+# shards the DataLoader, attaches GradSync (1/world folded into FusedAdam) - both ranks must hold identical parameters, equal to
+# a one-process simulation of the two shards (trainer/base_trainer.py:26-27 semantics: per-replica BatchNorm, averaged gradients)
+def _trainer_worker(rank, world, port, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import emu_lib
+    from oracle import plan
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+    n, ci, sl = 2, 4, 64
+    m = importlib.import_module(PKG_NAME + ".model").Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+    m._engine_override = eng
+    crit = importlib.import_module(PKG_NAME + ".loss").mse_loss()
+    crit._engine_override = eng
+    opt = importlib.import_module(PKG_NAME + ".optim").FusedAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    opt._engine_override = eng
+    ds = importlib.import_module(PKG_NAME + ".dataset").Dataset(n_items=12, sample_length=sl, seed=1)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)          # the GLOBAL batch, as train.py builds it
+    cfg = {"root_dir": tmpdir, "experiment_name": "dp", "trainer": {"epochs": 1, "save_checkpoint_interval": 1}}
+    tr = importlib.import_module(PKG_NAME + ".trainer").Trainer(cfg, False, m, crit, opt, loader, None)
+    assert dist.is_initialized() and tr.world == world and tr.rank == rank
+    assert tr.train_data_loader.batch_size == 2 and len(tr.train_data_loader) == 3
+    assert m.grad_sync is not None and m.grad_sync.scale_in_optimizer and opt.grad_scale == 0.5
+    tr.train()
+    torch.save({k: v.detach().clone() for k, v in m.named_parameters()}, os.path.join(tmpdir, f"params{rank}.pt"))
+
+
+def test_trainer_under_torchrun_env_trains_data_parallel(tmp_path):
+    world = 2
+    mp.spawn(_trainer_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    p0 = torch.load(os.path.join(str(tmp_path), "params0.pt"))
+    p1 = torch.load(os.path.join(str(tmp_path), "params1.pt"))
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k                                        # identical replicas after 3 steps
+    assert os.path.exists(os.path.join(str(tmp_path), "dp", "checkpoints", "latest_model.tar"))     # written once, by rank 0
+    # one-process simulation: per step, each shard's gradients from the same parameters (its own BatchNorm statistics),
+    # summed in fp32 (the all-reduce), 1/2 applied inside the Adam step
+    import emu_lib
+    from oracle import plan
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+    n, ci, sl = 2, 4, 64
+    m = importlib.import_module(PKG_NAME + ".model").Model(n_layers=n, channels_interval=ci)
+    m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+    m._engine_override = eng
+    m.train()
+    crit = importlib.import_module(PKG_NAME + ".loss").mse_loss()
+    crit._engine_override = eng
+    opt = importlib.import_module(PKG_NAME + ".optim").FusedAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    opt._engine_override = eng
+    opt.grad_scale = 0.5
+    ds = importlib.import_module(PKG_NAME + ".dataset").Dataset(n_items=12, sample_length=sl, seed=1)
+    for step in range(3):
+        total = None
+        for r in range(world):                       # DistributedSampler(shuffle=False): rank r holds items r, r+2, r+4, ...
+            items = [ds[r + world * (2 * step + j)] for j in range(2)]
+            mix = torch.stack([it[0] for it in items])
+            cl = torch.stack([it[1] for it in items])
+            opt.zero_grad(set_to_none=True)
+            crit(cl, m(mix)).backward()
+            g = [p.grad.clone() for p in m.parameters()]
+            total = g if total is None else [a + b for a, b in zip(total, g)]
+        for p, g in zip(m.parameters(), total):
+            p.grad = g
+        opt.step()
+    for k, p in m.named_parameters():
+        assert torch.equal(p.detach(), p0[k]), k

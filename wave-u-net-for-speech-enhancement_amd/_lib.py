@@ -15,6 +15,7 @@ EXPORTS = [
     "wunet_loss_backward", "wunet_layer_info", "wunet_num_conv_layers", "wunet_op_conv1d",
     "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
     "wunet_adam_step", "wunet_set_h3", "wunet_op_conv1d_split", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split",
+    "wunet_backward_range_async", "wunet_backward_join",
 ]
 
 _vp = ctypes.c_void_p
@@ -34,6 +35,8 @@ def declare(lib):
     lib.wunet_forward.argtypes = [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]
     lib.wunet_backward.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.wunet_backward_range.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
+    lib.wunet_backward_range_async.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]
+    lib.wunet_backward_join.argtypes = [_vp, _vp]
     lib.wunet_loss_scratch_bytes.restype = _sz
     lib.wunet_loss_scratch_bytes.argtypes = []
     lib.wunet_loss_forward.argtypes = [_i, _vp, _vp, _sz, _vp, _vp, _vp]
@@ -45,7 +48,7 @@ def declare(lib):
     for name in ("wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split"):
         getattr(lib, name).argtypes = [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]
     lib.wunet_adam_step.argtypes = [_i, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, ctypes.c_double, ctypes.c_double,
-                                    ctypes.c_double, ctypes.c_longlong, _vp]
+                                    ctypes.c_double, ctypes.c_longlong, ctypes.c_double, _vp, _vp, _vp]
     lib.wunet_set_h3.argtypes = [_vp, _i]
     lib.wunet_profile_enable.argtypes = [_i]
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]

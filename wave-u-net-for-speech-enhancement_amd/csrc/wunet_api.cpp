@@ -6,6 +6,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -296,10 +298,12 @@ struct wunet_ctx {
     size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_slot;   // float offsets
     size_t fslot_off, wmax_off;   // forward segment: WUNET_SLOT_FLOATS per layer (x / weight scales, activation bound), partial max |W|
     size_t h3_wf_halfs, h3_wb_halfs;
-    // side stream for the weight-gradient GEMMs (off the backward's critical chain), created lazily per device
-    int side_dev = -1;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // side stream for the weight-gradient GEMMs (off the backward's critical chain): one per device the ctx is used on, created
+    // lazily under the lock and never replaced, so replicas of one shape on several devices (or threads) do not disturb each other.
+    // Everything else in the ctx is immutable after wunet_create / wunet_set_h3.
+    struct Side { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    std::map<int, Side> side;
+    std::mutex side_lock;
 };
 
 namespace {
@@ -618,19 +622,22 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     return 0;
 }
 
-int ensure_side_stream(wunet_ctx* c)
+// the side stream + fork / join events of the CURRENT device (nullptr + error text on failure)
+wunet_ctx::Side* side_for_current_device(wunet_ctx* c)
 {
     int dev = 0;
-    hipGetDevice(&dev);
-    if (c->side_dev != dev) {
-        if (c->side) { hipStreamDestroy(c->side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); c->side = nullptr; }
-        if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess)
-            return fail(WUNET_E_RUNTIME, "cannot create the side stream");
-        c->side_dev = dev;
+    if (hipGetDevice(&dev) != hipSuccess) { fail(WUNET_E_RUNTIME, "hipGetDevice failed"); return nullptr; }
+    std::lock_guard<std::mutex> g(c->side_lock);
+    auto it = c->side.find(dev);
+    if (it != c->side.end()) return &it->second;
+    wunet_ctx::Side sd;
+    if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ev_join, hipEventDisableTiming) != hipSuccess) {
+        fail(WUNET_E_RUNTIME, "cannot create the side stream of device %d", dev);
+        return nullptr;
     }
-    return 0;
+    return &(c->side[dev] = sd);
 }
 }  // namespace
 
@@ -683,7 +690,9 @@ int wunet_set_h3(wunet_ctx* ctx, int enable)
 void wunet_destroy(wunet_ctx* ctx)
 {
     if (!ctx) return;
-    if (ctx->side) { hipStreamDestroy(ctx->side); hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join); }
+    for (auto& kv : ctx->side) {
+        hipStreamDestroy(kv.second.stream); hipEventDestroy(kv.second.ev_fork); hipEventDestroy(kv.second.ev_join);
+    }
     delete ctx;
 }
 
@@ -942,9 +951,12 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     return WUNET_OK;
 }
 
-int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* params, const float* enhanced,
-                         const float* grad_enhanced, void* workspace, float* const* grads,
-                         int layer_begin, int layer_end, void* stream)
+}  // extern "C"
+
+namespace {
+int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* params, const float* enhanced,
+                        const float* grad_enhanced, void* workspace, float* const* grads,
+                        int layer_begin, int layer_end, void* stream, bool join)
 {
     if (!c || !noisy || !params || !enhanced || !grad_enhanced || !workspace || !grads) return fail(WUNET_E_ARG, "null argument");
     if (layer_begin < 0 || layer_end > c->NL || layer_begin >= layer_end) return fail(WUNET_E_ARG, "bad layer range");
@@ -953,9 +965,10 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
     const int NL = c->NL, n = c->n;
     // weight gradients run on a side stream: they only depend on g_z and x of their own layer, so the HBM-bound
     // gradient-assembly kernels of the next layers overlap with them instead of idling the matrix cores
-    if (ensure_side_stream(c)) return WUNET_E_RUNTIME;
+    wunet_ctx::Side* side = side_for_current_device(c);
+    if (!side) return WUNET_E_RUNTIME;
     static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr;     // A/B switch for measurements
-    hipStream_t sd = (g_prof_on || no_side) ? st : c->side;      // the per-kernel profiler serialises everything on one stream
+    hipStream_t sd = (g_prof_on || no_side) ? st : side->stream;  // the per-kernel profiler serialises everything on one stream
 
     if (layer_end == NL) {
         if (c->h3) hipMemsetAsync(ws + c->h3_slot, 0, 8 * sizeof(float), st);     // 32 zero bytes: the zero page of the DMA-staged weight gradient
@@ -1081,8 +1094,8 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
         //      + deterministic reduce
         {
             if (sd != st) {
-                hipEventRecord(c->ev_fork, st);
-                hipStreamWaitEvent(sd, c->ev_fork, 0);
+                if (hipEventRecord(side->ev_fork, st) != hipSuccess || hipStreamWaitEvent(sd, side->ev_fork, 0) != hipSuccess)
+                    return fail(WUNET_E_RUNTIME, "fork onto the weight-gradient stream failed");
             }
             const float* xin = i == 0 ? noisy : ws + l.xin;
             const size_t nw = (size_t)l.cout * l.cin * l.taps;
@@ -1174,10 +1187,43 @@ int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* p
             }
         }
     }
-    if (sd != st) {          // join: the caller's stream sees every gradient
-        hipEventRecord(c->ev_join, sd);
-        hipStreamWaitEvent(st, c->ev_join, 0);
+    // join: the caller's stream sees every weight gradient.  An un-joined range (wunet_backward_range_async) leaves them to
+    // wunet_backward_join - except the range that ends the backward, which always joins: the next forward overwrites the
+    // operands the side stream is still reading.
+    if (sd != st && (join || layer_begin == 0)) {
+        if (hipEventRecord(side->ev_join, sd) != hipSuccess || hipStreamWaitEvent(st, side->ev_join, 0) != hipSuccess)
+            return fail(WUNET_E_RUNTIME, "join of the weight-gradient stream failed");
     }
+    return WUNET_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int wunet_backward_range(wunet_ctx* c, const float* noisy, const float* const* params, const float* enhanced,
+                         const float* grad_enhanced, void* workspace, float* const* grads,
+                         int layer_begin, int layer_end, void* stream)
+{
+    return backward_range_impl(c, noisy, params, enhanced, grad_enhanced, workspace, grads, layer_begin, layer_end, stream, true);
+}
+
+int wunet_backward_range_async(wunet_ctx* c, const float* noisy, const float* const* params, const float* enhanced,
+                               const float* grad_enhanced, void* workspace, float* const* grads,
+                               int layer_begin, int layer_end, void* stream)
+{
+    return backward_range_impl(c, noisy, params, enhanced, grad_enhanced, workspace, grads, layer_begin, layer_end, stream, false);
+}
+
+int wunet_backward_join(wunet_ctx* c, void* stream)
+{
+    if (!c) return fail(WUNET_E_ARG, "null ctx");
+    wunet_ctx::Side* side = side_for_current_device(c);
+    if (!side) return WUNET_E_RUNTIME;
+    static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr;
+    if (g_prof_on || no_side) return WUNET_OK;                   // the weight gradients ran on the caller's stream
+    if (hipEventRecord(side->ev_join, side->stream) != hipSuccess ||
+        hipStreamWaitEvent((hipStream_t)stream, side->ev_join, 0) != hipSuccess)
+        return fail(WUNET_E_RUNTIME, "join of the weight-gradient stream failed");
     return WUNET_OK;
 }
 
@@ -1185,7 +1231,7 @@ int wunet_backward(wunet_ctx* c, const float* noisy, const float* const* params,
                    const float* grad_enhanced, void* workspace, float* const* grads, void* stream)
 {
     if (!c) return fail(WUNET_E_ARG, "null ctx");
-    return wunet_backward_range(c, noisy, params, enhanced, grad_enhanced, workspace, grads, 0, c->NL, stream);
+    return backward_range_impl(c, noisy, params, enhanced, grad_enhanced, workspace, grads, 0, c->NL, stream, true);
 }
 
 size_t wunet_loss_scratch_bytes(void) { return 256 * sizeof(double); }
@@ -1217,13 +1263,20 @@ int wunet_loss_backward(int kind, const float* clean, const float* enhanced, con
 // ---------------------------------------------------------------------------- fused Adam
 int wunet_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                     float* const* exp_avg_sq, const size_t* numels, double lr, double beta1, double beta2, double eps,
-                    long long step, void* stream)
+                    long long step, double grad_scale, long long* step_dev, float* hyper_dev, void* stream)
 {
     if (n_tensors < 0 || (n_tensors > 0 && (!params || !grads || !exp_avg || !exp_avg_sq || !numels))) return fail(WUNET_E_ARG, "null argument");
-    if (step < 1) return fail(WUNET_E_ARG, "step must be >= 1");
+    if (!step_dev && step < 1) return fail(WUNET_E_ARG, "step must be >= 1");
+    if (step_dev && !hyper_dev) return fail(WUNET_E_ARG, "a device step counter needs the 2-float hyper buffer");
     hipStream_t st = (hipStream_t)stream;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    float step_size = 0.0f, bc2_sqrt = 1.0f;
+    if (step_dev) {
+        WUNET_LAUNCH(adam_hyper_kernel, dim3(1), dim3(1), 0, st, step_dev, lr, beta1, beta2, hyper_dev);
+        WUNET_CHECK_LAUNCH();
+    } else {
+        const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+        step_size = (float)(lr / bc1); bc2_sqrt = (float)sqrt(bc2);
+    }
     for (int base = 0; base < n_tensors; base += WUNET_ADAM_MAX) {
         AdamTable T{};
         const int cnt = n_tensors - base < WUNET_ADAM_MAX ? n_tensors - base : WUNET_ADAM_MAX;
@@ -1238,7 +1291,7 @@ int wunet_adam_step(int n_tensors, float* const* params, const float* const* gra
         if (bx < 1) bx = 1;
         if (bx > 256) bx = 256;
         WUNET_LAUNCH(adam_kernel, dim3((unsigned)bx, cnt), dim3(WUNET_THREADS), 0, st, T, (float)(1.0 - beta1), (float)beta2,
-                     (float)(1.0 - beta2), bc2_sqrt, (float)eps, step_size);
+                     (float)(1.0 - beta2), bc2_sqrt, (float)eps, step_size, (float)grad_scale, (const float*)(step_dev ? hyper_dev : nullptr));
         WUNET_CHECK_LAUNCH();
     }
     return WUNET_OK;

@@ -818,9 +818,14 @@ struct AdamTable {
     unsigned n[WUNET_ADAM_MAX];
 };
 
+// gscale: the gradient is multiplied by it first (1/world_size of the data-parallel average folded into the step: the same
+// rounding as a separate g.mul_(1/world) pass).  hyper != nullptr: {step_size, bc2_sqrt} come from device memory
+// (adam_hyper_kernel: the step counter lives on the device, so a captured graph replays the right bias corrections).
 __global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float one_minus_b1, float b2, float one_minus_b2,
-                                                              float bc2_sqrt, float eps, float step_size)
+                                                              float bc2_sqrt, float eps, float step_size, float gscale,
+                                                              const float* hyper)
 {
+    if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }
     const int t = blockIdx.y;
     float* p = T.p[t];
     const float* g = T.g[t];
@@ -828,7 +833,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float 
     float* v = T.v[t];
     const unsigned n = T.n[t];
     for (unsigned i = blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += gridDim.x * WUNET_THREADS) {
-        const float gi = g[i];
+        const float gi = gscale == 1.0f ? g[i] : g[i] * gscale;
         float mi = m[i], vi = v[i];
         mi = mi + one_minus_b1 * (gi - mi);
         vi = vi * b2 + one_minus_b2 * gi * gi;
@@ -837,4 +842,15 @@ __global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float 
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         p[i] = p[i] - step_size * (mi / denom);
     }
+}
+
+// step counter on the device: *step += 1, then the bias-corrected step size lr / (1 - b1^t) and sqrt(1 - b2^t) in double like
+// torch's host arithmetic (one thread)
+__global__ void adam_hyper_kernel(long long* step, double lr, double beta1, double beta2, float* hyper)
+{
+    const long long t = *step + 1;
+    *step = t;
+    const double bc1 = 1.0 - pow(beta1, (double)t), bc2 = 1.0 - pow(beta2, (double)t);
+    hyper[0] = (float)(lr / bc1);
+    hyper[1] = (float)sqrt(bc2);
 }

@@ -1,6 +1,7 @@
 """Python face of the C ABI: owns per-shape contexts, turns torch tensors into raw device pointers
 and enqueues the HIP path on torch's current stream.  PyTorch is plumbing here (device memory,
 streams); every arithmetic kernel lives in csrc/."""
+import collections
 import ctypes
 import os
 import threading
@@ -27,7 +28,10 @@ class Engine:
         # GEMM arithmetic of the levels >= 32 samples (include/wunet_hip.h: wunet_set_h3): 1 = fp16-split MFMA where the grid
         # fills the chip (default), 0 = fp32 MFMA everywhere (WUNET_H3=0), 2 = fp16-split wherever it can run (tests)
         self.h3 = int(os.environ.get("WUNET_H3", "1")) if h3 is None else int(h3)
-        self._ctx = {}
+        # contexts are keyed by shape AND device (the ctx owns a weight-gradient side stream per device it runs on; replicas
+        # of one shape on several devices - a stock nn.DataParallel wrap, trainer/base_trainer.py:26-27 - get their own),
+        # least-recently-used ones are destroyed beyond MAX_CONTEXTS (variable-length inference would otherwise leak one per shape)
+        self._ctx = collections.OrderedDict()
         self._lock = threading.Lock()
 
     # ------------------------------------------------------------------ helpers
@@ -35,8 +39,10 @@ class Engine:
         if rc != 0:
             raise WunetError(f"wunet error {rc}: {self.lib.wunet_last_error().decode()}")
 
-    def _ctx_for(self, n_layers, ci, batch, length):
-        key = (n_layers, ci, batch, length)
+    MAX_CONTEXTS = 32
+
+    def _ctx_for(self, n_layers, ci, batch, length, device=None):
+        key = (n_layers, ci, batch, length, str(device))
         with self._lock:
             h = self._ctx.get(key)
             if h is None:
@@ -45,6 +51,11 @@ class Engine:
                 if self.h3:
                     self._check(self.lib.wunet_set_h3(h, self.h3))
                 self._ctx[key] = h
+                while len(self._ctx) > self.MAX_CONTEXTS:
+                    _, old = self._ctx.popitem(last=False)
+                    self.lib.wunet_destroy(old)      # (HIP defers the side stream's destruction until its work has drained)
+            else:
+                self._ctx.move_to_end(key)
         return h
 
     def _require(self, t, name):
@@ -84,7 +95,7 @@ class Engine:
         for t in list(running) + list(nbt):
             self._require(t, "buffer")
         B, _, T = noisy.shape
-        h = self._ctx_for(n_layers, ci, B, T)
+        h = self._ctx_for(n_layers, ci, B, T, noisy.device)
         nbytes = self.lib.wunet_workspace_bytes(h, 1 if with_backward else 0)
         ws = torch.empty(nbytes // 4, dtype=torch.float32, device=noisy.device)
         out = torch.empty_like(noisy)
@@ -94,20 +105,29 @@ class Engine:
                                                out.data_ptr(), self._stream(noisy.device)))
         return out, ws
 
-    def backward(self, n_layers, ci, noisy, params, enhanced, grad_enhanced, ws, grads, layer_range=None):
+    def backward(self, n_layers, ci, noisy, params, enhanced, grad_enhanced, ws, grads, layer_range=None, join=True):
+        """join=False: the caller's stream does not wait for the range's weight gradients (side stream); make a stream see them
+        with `join_weight_gradients` (parallel.GradSync does, on the stream that launches the bucket's all-reduce)."""
         B, _, T = noisy.shape
-        h = self._ctx_for(n_layers, ci, B, T)
+        h = self._ctx_for(n_layers, ci, B, T, noisy.device)
         self._require(grad_enhanced, "grad_output")
         nl = 2 * n_layers + 1
         lb, le = layer_range if layer_range is not None else (0, nl)
+        fn = self.lib.wunet_backward_range if join else self.lib.wunet_backward_range_async
         with self._device_guard(noisy.device):
-            self._check(self.lib.wunet_backward_range(h, noisy.data_ptr(), self._ptrs(params), enhanced.data_ptr(),
-                                                      grad_enhanced.data_ptr(), ws.data_ptr(), self._ptrs(grads),
-                                                      lb, le, self._stream(noisy.device)))
+            self._check(fn(h, noisy.data_ptr(), self._ptrs(params), enhanced.data_ptr(), grad_enhanced.data_ptr(), ws.data_ptr(),
+                           self._ptrs(grads), lb, le, self._stream(noisy.device)))
+
+    def join_weight_gradients(self, n_layers, ci, noisy):
+        """Torch's current stream waits for everything the weight-gradient side stream has been given so far."""
+        B, _, T = noisy.shape
+        h = self._ctx_for(n_layers, ci, B, T, noisy.device)
+        with self._device_guard(noisy.device):
+            self._check(self.lib.wunet_backward_join(h, self._stream(noisy.device)))
 
     def layer_output(self, n_layers, ci, batch, length, ws, layer):
         """Raw conv output (pre-BatchNorm) of conv layer `layer` as a view into a workspace (tests/profiling)."""
-        h = self._ctx_for(n_layers, ci, batch, length)
+        h = self._ctx_for(n_layers, ci, batch, length, ws.device)
         off, ch, ln = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
         self._check(self.lib.wunet_layer_info(h, layer, ctypes.byref(off), ctypes.byref(ch), ctypes.byref(ln)))
         return ws[off.value: off.value + batch * ch.value * ln.value].view(batch, ch.value, ln.value)
@@ -136,8 +156,9 @@ class Engine:
         return g
 
 
-def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step):
-    """One fused Adam step over a list of tensors."""
+def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None, hyper_dev=None):
+    """One fused Adam step over a list of tensors.  step_dev (int64 device scalar) + hyper_dev (2 floats):
+    the step count lives on the device and the call increments it (capturable in a hipGraph); otherwise `step` is the host's."""
     for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
         self._require(t, "adam tensor")
     n = len(params)
@@ -146,7 +167,9 @@ def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, 
     with self._device_guard(dev):
         self._check(self.lib.wunet_adam_step(n, self._ptrs(params), self._ptrs(grads), self._ptrs(exp_avg),
                                              self._ptrs(exp_avg_sq), numels, float(lr), float(beta1), float(beta2),
-                                             float(eps), int(step), self._stream(dev)))
+                                             float(eps), int(step), float(grad_scale),
+                                             step_dev.data_ptr() if step_dev is not None else None,
+                                             hyper_dev.data_ptr() if hyper_dev is not None else None, self._stream(dev)))
 
 
 Engine.adam_step = _adam_step

@@ -36,6 +36,9 @@ class _Level(nn.Module):
 class _WaveUNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, need_grad, noisy, *params):
+        if noisy.requires_grad:           # before anything runs: a training-mode forward updates the running statistics
+            raise NotImplementedError("gradient w.r.t. the waveform input is not part of the reference hot path "
+                                      "(encoder[0] needs no data gradient); detach the input")
         engine = owner._engine()
         params = [p.detach() for p in params]
         running, nbt = owner._wunet_buffers()
@@ -46,9 +49,6 @@ class _WaveUNetFn(torch.autograd.Function):
         ctx.training = training
         ctx.ws = ws if need_grad else None
         ctx.save_for_backward(noisy, out, *params)
-        if noisy.requires_grad:
-            raise NotImplementedError("gradient w.r.t. the waveform input is not part of the reference hot path "
-                                      "(encoder[0] needs no data gradient); detach the input")
         return out
 
     @staticmethod
@@ -56,6 +56,9 @@ class _WaveUNetFn(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("backward through eval-mode BatchNorm is not implemented by the HIP path "
                                       "(the reference only back-propagates in training mode, trainer/trainer.py:34-38)")
+        if ctx.ws is None:
+            raise RuntimeError("backward through this forward has already run: its workspace (the saved activations) was "
+                               "released; run the forward again (retain_graph=True cannot keep it)")
         owner = ctx.owner
         noisy, out, *params = ctx.saved_tensors
         engine = owner._engine()

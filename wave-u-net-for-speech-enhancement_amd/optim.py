@@ -3,24 +3,55 @@
 Drop-in for the optimiser the reference builds in train.py:31-35
 (`torch.optim.Adam(params=model.parameters(), lr=..., betas=(beta1, beta2))`): same constructor arguments the
 reference uses, same update rule and operation order as torch's single-tensor path (eps=1e-8, weight_decay=0,
-amsgrad=False), same `state_dict()` layout ("step", "exp_avg", "exp_avg_sq" per parameter) so the reference's
-checkpoints (trainer/base_trainer.py:62-124) load both ways - but one or two HIP launches over all 102 tensors
-instead of ~10 multi-tensor ATen kernels.
+amsgrad=False), same `state_dict()` layout ("step", "exp_avg", "exp_avg_sq" per parameter; param_groups carry every key
+torch.optim.Adam's do) so the reference's checkpoints (trainer/base_trainer.py:62-124) load both ways - but one or two HIP
+launches over all 102 tensors instead of ~10 multi-tensor ATen kernels.
+
+`grad_scale` (attribute): every gradient is multiplied by it inside the step - the 1/world_size of the data-parallel average
+(parallel.GradSync(scale_in_optimizer=True)).
+`device_step=True`: the step counter lives on the device (incremented by the step's own kernel, bias corrections computed there
+in double), so forward + loss + backward + step can be captured in one hipGraph and replayed (trainer.Trainer(graph=True));
+the host-side `state["step"]` is kept in step by `advance_host_step()` after every replay.
 """
 import torch
 
 from .engine import default_engine
 
+_ADAM_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
+                      fused=None, decoupled_weight_decay=False)
+
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, device_step=False):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0):
             raise ValueError("invalid Adam hyper-parameters")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, **_ADAM_DEFAULTS))
         self._engine_override = None
+        self.grad_scale = 1.0
+        self.device_step = device_step
+        self._dev = {}            # group index -> (int64 step counter, 2-float hyper buffer) on the parameters' device
 
     def _engine(self):
         return self._engine_override if self._engine_override is not None else default_engine()
+
+    def load_state_dict(self, state_dict):
+        for g in state_dict["param_groups"]:
+            if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("FusedAdam implements the reference's Adam (train.py:31-35: weight_decay=0, amsgrad=False, "
+                                 "maximize=False); the checkpoint asks for something else")
+        super().load_state_dict(state_dict)
+        for g in self.param_groups:
+            for k, v in _ADAM_DEFAULTS.items():
+                g.setdefault(k, v)
+        self._dev = {}            # re-seeded from the loaded host step at the next step()
+
+    def advance_host_step(self, n=1):
+        """After replaying a captured graph that contains step(): the device counter advanced, bring state["step"] along."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if st:
+                    st["step"] += n
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -28,7 +59,7 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps, gs, ms, vs = [], [], [], []
             step = None
             for p in group["params"]:
@@ -49,5 +80,12 @@ class FusedAdam(torch.optim.Optimizer):
                 ps.append(p); gs.append(g); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
             if ps:
                 b1, b2 = group["betas"]
-                self._engine().adam_step(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], step)
+                step_dev = hyper_dev = None
+                if self.device_step:
+                    if gi not in self._dev:          # (outside any capture: the first eager step creates and seeds it)
+                        self._dev[gi] = (torch.full((), step - 1, dtype=torch.int64, device=ps[0].device),
+                                         torch.zeros(2, dtype=torch.float32, device=ps[0].device))
+                    step_dev, hyper_dev = self._dev[gi]
+                self._engine().adam_step(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], step, self.grad_scale,
+                                         step_dev, hyper_dev)
         return loss

@@ -38,13 +38,23 @@ def bucket_ranges(param_numels, n_conv_layers, n_buckets):
 
 class GradSync:
     """Attach with `model.grad_sync = GradSync(...)`; the model's backward then runs the layer
-    ranges through wunet_backward_range and enqueues one asynchronous all-reduce per finished bucket."""
+    ranges through wunet_backward_range_async and enqueues one asynchronous all-reduce per finished bucket.
 
-    def __init__(self, process_group=None, n_buckets=4, always_reduce=False):
+    Stream structure on the GPU (one process per GPU): the backward's data-gradient chain runs on torch's current stream S, the
+    weight gradients on the library's side stream W.  Only the collective needs a bucket's weight gradients, so S is never made
+    to wait for W at a bucket boundary: a launch stream C waits for S (event) and for W (wunet_backward_join) and the
+    all-reduce is enqueued from C; RCCL's own stream then waits for C.  S waits for the collectives once, after the last range.
+
+    scale_in_optimizer=True: the 1/world_size of the average is left to the optimiser step (optim.FusedAdam.grad_scale - the
+    same rounding, four launches and 2 x 40 MB of traffic less); the default scales the buckets here so any optimiser works."""
+
+    def __init__(self, process_group=None, n_buckets=4, always_reduce=False, scale_in_optimizer=False):
         self.group = process_group
         self.n_buckets = n_buckets
         self.always_reduce = always_reduce      # issue the collectives even at world_size 1 (single-GPU RCCL smoke test)
+        self.scale_in_optimizer = scale_in_optimizer
         self._ranges = {}
+        self._launch_streams = {}
 
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -55,16 +65,34 @@ class GradSync:
             self._ranges[key] = bucket_ranges([p.numel() for p in params], n_conv_layers, self.n_buckets)
         return self._ranges[key]
 
+    def _launch_stream(self, device):
+        if device not in self._launch_streams:
+            self._launch_streams[device] = torch.cuda.Stream(device=device)
+        return self._launch_streams[device]
+
     def run(self, engine, owner, noisy, params, out, grad_out, ws, grads, flat):
         nl = 2 * owner.n_layers + 1
         world = self.world_size()
+        reduce = world > 1 or (self.always_reduce and dist.is_initialized())
+        on_gpu = noisy.is_cuda
         pending = []
         for lb, le, fb, fe in self.ranges_for(params, nl):
             engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out, ws, grads,
-                            layer_range=(lb, le))
-            if world > 1 or (self.always_reduce and dist.is_initialized()):
-                seg = flat[fb:fe]
-                pending.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg))
+                            layer_range=(lb, le), join=not (reduce and on_gpu))
+            if not reduce:
+                continue
+            seg = flat[fb:fe]
+            if on_gpu:
+                main = torch.cuda.current_stream(noisy.device)
+                launch = self._launch_stream(noisy.device)
+                launch.wait_stream(main)                                    # the range's data-path kernels (BN, bias, head grads)
+                with torch.cuda.stream(launch):
+                    engine.join_weight_gradients(owner.n_layers, owner.channels_interval, noisy)   # ... and its weight gradients
+                    work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            pending.append((work, seg))
         for work, seg in pending:
             work.wait()                  # stream-level dependency on the RCCL stream, host does not block
-            seg.mul_(1.0 / world)
+            if not self.scale_in_optimizer:
+                seg.mul_(1.0 / world)

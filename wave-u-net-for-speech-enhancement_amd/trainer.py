@@ -6,11 +6,17 @@ Same constructor as the reference's Trainer (/root/reference/trainer/trainer.py:
 and the same `.train()` entry (train.py:51), covering the hot loop only (trainer/trainer.py:27-43,
 base_trainer.py:187-197): validation, TensorBoard and metrics are out of scope.
 Differences from the reference loop, all on the f2 list:
-  * one process per GPU (torchrun); the RCCL gradient all-reduce is attached to the model instead of
-    nn.DataParallel (base_trainer.py:26-27);
+  * one process per GPU: launched under torchrun (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the constructor joins the
+    process group itself (backend "nccl" = RCCL on a GPU box, "gloo" without one), pins the process to its GPU, re-wraps the
+    incoming DataLoader with a DistributedSampler (train.py:15-21 builds it without one; the reference's batch_size is the
+    GLOBAL batch that nn.DataParallel splits, base_trainer.py:26-27, so each rank loads batch_size / world_size items) and
+    attaches the RCCL gradient all-reduce to the model instead of nn.DataParallel;
   * host->device copies are non_blocking from pinned memory (train.py:20 sets pin_memory but copies synchronously);
   * the loss is accumulated on the device and read back once per epoch (trainer.py:40 syncs every step);
-  * checkpoints keep the reference's names and keys (base_trainer.py:83-124) so either side can resume.
+  * `"graph": true` in the trainer config (or WUNET_GRAPH=1): after a few eager steps the whole step - forward, loss, backward,
+    Adam (optim.FusedAdam with its device-side step counter) - is captured once in a hipGraph (torch.cuda.CUDAGraph) on static
+    input buffers and replayed: ~270 kernel launches become one graph launch per step;
+  * checkpoints keep the reference's names and keys (base_trainer.py:83-124) so either side can resume; only rank 0 writes.
 """
 import os
 from pathlib import Path
@@ -18,25 +24,50 @@ from pathlib import Path
 import torch
 import torch.distributed as dist
 
+from .optim import FusedAdam
 from .parallel import GradSync
+
+GRAPH_WARMUP_STEPS = 3
 
 
 class Trainer:
     def __init__(self, config, resume, model, loss_function, optimizer, train_dataloader, validation_dataloader=None):
+        env_world = int(os.environ.get("WORLD_SIZE", "1"))
+        self._own_pg = False
+        if env_world > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            self._own_pg = True
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.device = torch.device("cuda", local_rank) if torch.cuda.is_available() else torch.device("cpu")
+        if torch.cuda.is_available():
+            self.device = torch.device("cuda", local_rank)
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device("cpu")
         self.model = model.to(self.device)
-        if self.world > 1:
-            self.model.grad_sync = GradSync()
         self.loss_function = loss_function
         self.optimizer = optimizer
-        self.train_data_loader = train_dataloader
+        fused = isinstance(optimizer, FusedAdam)
+        if self.world > 1:
+            self.model.grad_sync = GradSync(scale_in_optimizer=fused)
+            if fused:
+                optimizer.grad_scale = 1.0 / self.world
+        self.train_data_loader = self._shard_loader(train_dataloader)
         self.validation_data_loader = validation_dataloader      # accepted for signature compatibility, unused
         tcfg = config["trainer"]
         self.epochs = tcfg["epochs"]
         self.save_checkpoint_interval = tcfg.get("save_checkpoint_interval", 0)
+        self.use_graph = bool(tcfg.get("graph", os.environ.get("WUNET_GRAPH", "0") not in ("", "0")))
+        if self.use_graph and not (fused and self.device.type == "cuda" and self.world == 1):
+            # (RCCL collectives inside a captured graph are left for a later round: the eager path overlaps them already)
+            self.use_graph = False
+        if self.use_graph:
+            optimizer.device_step = True
+        self._graph = None
+        self._static = None
+        self._eager_steps = 0
         self.start_epoch = 1
         self.best_score = float("-inf")
         root = Path(os.path.expanduser(config.get("root_dir", "."))).absolute() / config.get("experiment_name", "exp")
@@ -44,6 +75,26 @@ class Trainer:
         self.epoch_losses = []
         if resume:
             self._resume_checkpoint()
+
+    # ---- data: every rank its own shard of each global batch (DataParallel's split, base_trainer.py:26-27)
+    def _shard_loader(self, loader):
+        if self.world == 1 or loader is None:
+            return loader
+        from torch.utils.data import DataLoader
+        from torch.utils.data.distributed import DistributedSampler
+        if isinstance(getattr(loader, "sampler", None), DistributedSampler):
+            return loader
+        if not isinstance(loader, DataLoader):
+            raise TypeError("Trainer under torchrun needs a torch DataLoader (or one that already carries a DistributedSampler) "
+                            "to shard the data; got " + type(loader).__name__)
+        if loader.batch_size is None or loader.batch_size % self.world != 0:
+            raise ValueError(f"batch_size={loader.batch_size} (the global batch, as nn.DataParallel would split it) must be a "
+                             f"multiple of the world size {self.world}")
+        shuffle = isinstance(loader.sampler, torch.utils.data.RandomSampler)
+        sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.rank, shuffle=shuffle, drop_last=True)
+        return DataLoader(loader.dataset, batch_size=loader.batch_size // self.world, sampler=sampler,
+                          num_workers=loader.num_workers, pin_memory=loader.pin_memory, drop_last=True,
+                          collate_fn=loader.collate_fn)
 
     # ---- checkpoints: reference layout (base_trainer.py:62-124)
     def _resume_checkpoint(self):
@@ -64,19 +115,58 @@ class Trainer:
         torch.save(state, (self.checkpoints_dir / "latest_model.tar").as_posix())
         torch.save(state["model"], (self.checkpoints_dir / f"model_{str(epoch).zfill(4)}.pth").as_posix())
 
-    # ---- the hot loop (trainer/trainer.py:27-43)
+    # ---- one step of the hot loop (trainer/trainer.py:34-38)
+    def _eager_step(self, mixture, clean):
+        self.optimizer.zero_grad(set_to_none=True)
+        enhanced = self.model(mixture)
+        loss = self.loss_function(clean, enhanced)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _capture(self, mixture, clean):
+        """The step on static buffers, captured once (after the eager warm-up steps have created every lazily-built object:
+        contexts, side stream, LDS attributes, optimiser state, device step counter)."""
+        self._static = (mixture.clone(), clean.clone())
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            enhanced = self.model(self._static[0])
+            loss = self.loss_function(self._static[1], enhanced)
+            loss.backward()
+            self.optimizer.step()               # (host side of step(): state["step"] += 1 happened once, here)
+            self._static_loss = loss.detach()
+        self._graph = graph
+        # capture does not execute: undo the host-side count of the captured call; every replay counts itself
+        self.optimizer.advance_host_step(-1)
+
+    def _step(self, mixture, clean):
+        if not self.use_graph:
+            return self._eager_step(mixture, clean)
+        if self._graph is None:
+            if self._eager_steps < GRAPH_WARMUP_STEPS:
+                self._eager_steps += 1
+                return self._eager_step(mixture, clean)
+            self._capture(mixture, clean)
+        if mixture.shape != self._static[0].shape:          # a ragged last batch: eager (same kernels, same numbers)
+            loss = self._eager_step(mixture, clean)
+            return loss
+        self._static[0].copy_(mixture, non_blocking=True)
+        self._static[1].copy_(clean, non_blocking=True)
+        self._graph.replay()
+        self.optimizer.advance_host_step(1)
+        return self._static_loss
+
     def _train_epoch(self, epoch):
+        sampler = getattr(self.train_data_loader, "sampler", None)
+        if hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(epoch)
         loss_total = torch.zeros((), device=self.device)
         n = 0
         for mixture, clean, _name in self.train_data_loader:
             mixture = mixture.to(self.device, non_blocking=True)
             clean = clean.to(self.device, non_blocking=True)
-            self.optimizer.zero_grad(set_to_none=True)
-            enhanced = self.model(mixture)
-            loss = self.loss_function(clean, enhanced)
-            loss.backward()
-            self.optimizer.step()
-            loss_total += loss.detach()
+            loss_total += self._step(mixture, clean)
             n += 1
         mean = (loss_total / max(n, 1)).item()          # the only device->host sync of the epoch
         self.epoch_losses.append(mean)
@@ -88,3 +178,6 @@ class Trainer:
             self._train_epoch(epoch)
             if self.save_checkpoint_interval != 0 and epoch % self.save_checkpoint_interval == 0:
                 self._save_checkpoint(epoch)
+        if self._own_pg and dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()

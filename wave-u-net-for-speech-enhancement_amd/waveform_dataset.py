@@ -156,10 +156,8 @@ class ShardLoader:
             raise ValueError("no item is at least sample_length long")
         self.device = torch.device(device)
         total = int(starts[-1] + lengths[-1]) if len(starts) else 0
-        noisy = np.memmap(prefix + ".noisy.f32", np.float32, "r", shape=(total,))
-        clean = np.memmap(prefix + ".clean.f32", np.float32, "r", shape=(total,))
-        self.noisy = torch.from_numpy(np.array(noisy)).to(self.device)                 # one upload; stays resident
-        self.clean = torch.from_numpy(np.array(clean)).to(self.device)
+        self.noisy = self._resident(prefix + ".noisy.f32", total)                       # one upload; stays resident
+        self.clean = self._resident(prefix + ".clean.f32", total)
         self.usable = torch.from_numpy(usable)
         self.starts = torch.from_numpy(starts)
         self.spare = torch.from_numpy(lengths - sample_length + 1)                      # number of valid window starts per item
@@ -167,6 +165,20 @@ class ShardLoader:
         self.steps = steps_per_epoch if steps_per_epoch is not None else max(1, len(usable) // batch_size)
         self.gen = torch.Generator().manual_seed(seed)
         self.ramp = torch.arange(sample_length, device=self.device)
+
+    UPLOAD_CHUNK = 1 << 26          # floats per staged piece (256 MB): the corpus is never copied into host RAM as a whole
+
+    def _resident(self, path, total):
+        """The flat float32 file as a tensor on self.device.  The file is memory-mapped (copy-on-write, so torch gets a writable
+        view without touching the pages); a CPU loader uses the mapping itself, a GPU loader uploads it piece by piece."""
+        mm = np.memmap(path, np.float32, "c", shape=(total,))
+        if self.device.type == "cpu":
+            return torch.from_numpy(mm)
+        out = torch.empty(total, dtype=torch.float32, device=self.device)
+        for a in range(0, total, self.UPLOAD_CHUNK):
+            b = min(total, a + self.UPLOAD_CHUNK)
+            out[a:b].copy_(torch.from_numpy(mm[a:b]))
+        return out
 
     def __len__(self):
         return self.steps
