@@ -47,7 +47,7 @@ struct Worker {
     const std::function<void()>* body = nullptr;
     // barriers
     int bar_count = 0, bar_gen = 0;
-    int wbar_count[4] = {0, 0, 0, 0}, wbar_gen[4] = {0, 0, 0, 0};
+    int wbar_count[EMU_MAX_WAVES] = {}, wbar_gen[EMU_MAX_WAVES] = {};
     std::vector<float> smem;
 };
 
@@ -117,7 +117,7 @@ static void run_block(Worker& w)
         f.sp = (void*)sp;
     }
     w.bar_count = 0;
-    for (int k = 0; k < 4; ++k) w.wbar_count[k] = 0;
+    for (int k = 0; k < EMU_MAX_WAVES; ++k) w.wbar_count[k] = 0;
     int remaining = n;
     while (remaining > 0) {
         for (int i = 0; i < n; ++i) {

@@ -26,15 +26,16 @@ struct dim3 {
 struct float4 { float x, y, z, w; };
 struct float2 { float x, y; };
 
+#define EMU_MAX_WAVES 8      // workgroups of up to 512 threads
 namespace emu {
 struct FiberState { dim3 tidx; int op_parity; };
 struct BlockState {
     dim3 bidx, bdim, gdim;
     float* dyn_smem;
-    float wave_a[4][2][64];
-    float wave_b[4][2][64];
-    unsigned short wave_a8[4][2][64][8];
-    unsigned short wave_b8[4][2][64][8];
+    float wave_a[EMU_MAX_WAVES][2][64];
+    float wave_b[EMU_MAX_WAVES][2][64];
+    unsigned short wave_a8[EMU_MAX_WAVES][2][64][8];
+    unsigned short wave_b8[EMU_MAX_WAVES][2][64][8];
 };
 FiberState& cur_fiber();
 BlockState& cur_block();

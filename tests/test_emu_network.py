@@ -133,7 +133,8 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
 @pytest.mark.parametrize("switch,h3,cfg", [("WUNET_PREP4", 2, (4, 20, 3, 1024)),          # operand passes: 4 samples per thread
                                            ("WUNET_NO_SKIP_FUSE", 2, (4, 16, 3, 1024)),   # decoder-side pass reads the skip itself
                                            ("WUNET_NO_PASSA_FAST", 2, (4, 20, 3, 1024)),  # generic upsample-transpose walk
-                                           ("WUNET_NO_PASSA_FUSE", 0, (4, 12, 5, 128))])  # separate BN-backward finalize + g_z
+                                           ("WUNET_NO_PASSA_FUSE", 0, (4, 12, 5, 128)),   # separate BN-backward finalize + g_z
+                                           ("WUNET_H3_PAIR", 2, (2, 24, 2, 1024))])       # conv_h3p_kernel: two tiles per block, shared double-buffered W
 def test_measurement_switches_are_bit_identical(switch, h3, cfg, monkeypatch):
     """The fused / re-mapped elementwise kernels of the default path compute exactly what the forms they replaced compute:
     one training step with and without the A/B switch gives the same output and the same gradients, bit for bit."""

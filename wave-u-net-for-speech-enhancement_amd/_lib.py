@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libwunet_hip.so")
+# (WUNET_LIB_PATH: measurement builds of the same library, e.g. kernel ablations - never set in production)
+LIB_PATH = os.environ.get("WUNET_LIB_PATH") or os.path.join(_HERE, "csrc", "libwunet_hip.so")
 
 EXPORTS = [
     "wunet_last_error", "wunet_create", "wunet_destroy", "wunet_workspace_bytes", "wunet_forward",

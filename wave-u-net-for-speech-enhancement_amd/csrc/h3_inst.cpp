@@ -20,6 +20,19 @@ int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3
     return -1;
 }
 
+#define WUNET_PCASE(T, M)                                                                                  \
+    if (taps == T && mrep == M) {                                                                          \
+        if (WUNET_ALLOW_BIG_LDS((conv_h3p_kernel<T, M>), smem) != 0) return -2;                            \
+        WUNET_LAUNCH((conv_h3p_kernel<T, M>), grid, dim3(2 * WUNET_THREADS), smem, st, a);                 \
+        return 0;                                                                                          \
+    }
+
+int wunet_launch_conv_h3p(const ConvH3Args& a, int taps, int mrep, dim3 grid, size_t smem, hipStream_t st)
+{
+    WUNET_PCASE(15, 2) WUNET_PCASE(15, 3) WUNET_PCASE(15, 4) WUNET_PCASE(5, 2) WUNET_PCASE(5, 3) WUNET_PCASE(5, 4)
+    return -1;
+}
+
 #define WUNET_WCASE(T, M, S, P)                                                                            \
     if (taps == T && mrep == M && nseg == S && tp == P) {                                                  \
         if (WUNET_ALLOW_BIG_LDS((wgrad_h3_kernel<T, M, S, P>), smem) != 0) return -2;                      \

@@ -556,6 +556,18 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
     return 0;
 }
 
+// conv_h3p_kernel (two position tiles per block) runs instead of conv_h3_kernel: L >= 256, whole tiles, an even number of them
+bool h3_conv_is_paired(int B, int L)
+{
+    // A/B switch, off by default: measured on MI355X the paired kernel is 3 % SLOWER per step (6.31 vs 6.11 ms) - one 512-thread
+    // block per CU runs its two halves in lockstep, so nothing overlaps their prologues, barriers and epilogues, which two
+    // independent 256-thread blocks do for each other
+    const char* pe = getenv("WUNET_H3_PAIR");
+    const int pair_env = pe ? atoi(pe) : 0;
+    const long long posn = (long long)B * L;
+    return pair_env && L >= 256 && (posn & 511) == 0;
+}
+
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr)
@@ -570,12 +582,23 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     const int ksplit = (nstage + sps - 1) / sps;
     a.stages_per_split = sps; a.split_stride = (size_t)B * rows * L;
 
-    snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d, %d>", taps, mrep, nseg);
-    prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
-    const size_t smem = (size_t)(2 * 4 * nseg * (256 / nseg + 16) + 2 * mrep * 5 * 64) * 16;
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
-    const dim3 grid((unsigned)(a.ntiles * a.mblocks), (unsigned)ksplit);
-    const int rc = wunet_launch_conv_h3(a, taps, mrep, nseg, grid, smem, st);
+    // paired tiles (conv_h3p_kernel: two tiles per 512-thread block, double-buffered shared W) for L >= 256 with an even tile count
+    const bool paired = h3_conv_is_paired(B, L);            // (A/B switch: WUNET_H3_PAIR=0)
+    int rc;
+    if (paired) {
+        snprintf(pname, sizeof pname, "conv_h3p_kernel<%d, %d>", taps, mrep);
+        prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
+        const size_t smem = (size_t)(2 * 2 * 4 * 272 + 2 * 2 * mrep * 5 * 64) * 16;
+        const dim3 grid((unsigned)((a.ntiles / 2) * a.mblocks), (unsigned)ksplit);
+        rc = wunet_launch_conv_h3p(a, taps, mrep, grid, smem, st);
+    } else {
+        snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d, %d>", taps, mrep, nseg);
+        prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
+        const size_t smem = (size_t)(2 * 4 * nseg * (256 / nseg + 16) + 2 * mrep * 5 * 64) * 16;
+        const dim3 grid((unsigned)(a.ntiles * a.mblocks), (unsigned)ksplit);
+        rc = wunet_launch_conv_h3(a, taps, mrep, nseg, grid, smem, st);
+    }
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d nseg=%d (rc %d)", taps, mrep, nseg, rc);
     return 0;
@@ -907,7 +930,8 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         WUNET_CHECK_LAUNCH();
         // 2c. BatchNorm statistics -> scale/shift for the consumers (+ running stats)
         if (ev_epi) {
-            const int nrows = l.first ? l.f.grid_x : (int)(((long long)c->B * l.L + 255) / 256) * (l.h3f_mtp / l.h3f_mrep);
+            int nrows = l.first ? l.f.grid_x : (int)(((long long)c->B * l.L + 255) / 256) * (l.h3f_mtp / l.h3f_mrep);
+            if (!l.first && h3_conv_is_paired(c->B, l.L)) nrows /= 2;            // conv_h3p_kernel: one row per tile pair
             WUNET_LAUNCH(xb_reduce_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, (const float*)xrows, nrows, fslot + (size_t)WUNET_SLOT_FLOATS * i + 4);
         } else if (split) {
             // sum the z-slices (+bias -> z) and reduce the BN statistics; short levels finish BN in the same launch
