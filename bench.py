@@ -113,9 +113,11 @@ def main():
                     help="train = the headline metric (BASELINE configs[2]/[3]); forward = eval-mode forward only "
                          "(configs[1], the enhancement.py path) - an extra measurement, same JSON shape")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam (f1)")
-    ap.add_argument("--gemm", choices=["split", "fp32"], default=None,
+    ap.add_argument("--gemm", choices=["split", "fp32", "bf16"], default=None,
                     help="GEMM arithmetic of the levels >= 32 samples: split = 3 x f16 MFMA on hi/lo fp16 halves of every fp32 "
-                         "operand, fp32 accumulation (default, == WUNET_H3=1); fp32 = v_mfma_f32_16x16x4_f32 everywhere (WUNET_H3=0)")
+                         "operand, fp32 accumulation (default, == WUNET_H3=1); fp32 = v_mfma_f32_16x16x4_f32 everywhere (WUNET_H3=0); "
+                         "bf16 = bf16 operands, one MFMA pass (WUNET_H3=3; BASELINE configs[4], extra measurements only: outside "
+                         "the 1e-4 fp32 parity bar)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the training step as ONE captured hipGraph (torch.cuda.CUDAGraph over forward + loss + backward + "
                          "fused Adam with its device-side step counter; SURVEY.md section 8 f2).  auto = off: measured on MI355X / "
@@ -126,8 +128,10 @@ def main():
     args = ap.parse_args()
 
     if args.gemm is not None:
-        os.environ["WUNET_H3"] = "1" if args.gemm == "split" else "0"
-    split_gemm = os.environ.get("WUNET_H3", "1") != "0"
+        os.environ["WUNET_H3"] = {"split": "1", "fp32": "0", "bf16": "3"}[args.gemm]
+    h3_mode = os.environ.get("WUNET_H3", "1")
+    split_gemm = h3_mode != "0"
+    bf16_gemm = h3_mode in ("3", "4")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -263,10 +267,11 @@ def main():
                     traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
             except (OSError, ValueError, KeyError):
                 pass
-            is_split = "_h3_" in top["kernel"]
-            peak = PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
+            is_split = "_h3" in top["kernel"]
+            is_bf = "bf16" in top["kernel"]
+            peak = PEAK_F16_MFMA_TFLOPS if is_bf else PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
             roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": peak,
-                        "peak_note": ("2500 TFLOP/s dense f16 MFMA / 3 passes per fp32-equivalent product" if is_split
+                        "peak_note": ("2500 TFLOP/s dense bf16 MFMA" if is_bf else "2500 TFLOP/s dense f16 MFMA / 3 passes per fp32-equivalent product" if is_split
                                       else "fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
@@ -293,7 +298,8 @@ def main():
                       if default_net else f"{args.frame}-sample frames/sec, {args.layers}-level Wave-U-Net, mode={args.mode} (extra)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (levels >= 32 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
+            "dtype": ("bf16 operands, f32 accumulate / BatchNorm / gradients (levels >= 32 samples: 1 x bf16 MFMA; the rest f32 MFMA)" if bf16_gemm
+                      else "f32 (levels >= 32 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
                       else "f32"),
             "data": "synthetic",
             "config": {"workload": f"unet_basic {args.layers}-level, {args.frame}-sample frames, batch={args.batch} per GPU, fp32, "
@@ -303,7 +309,7 @@ def main():
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
             "whole_step_tflops_per_gpu": per_gpu_fps * step_flop / 1e12,
             "whole_step_frac_of_fp32_peak": per_gpu_fps * step_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "gemm": "split" if split_gemm else "fp32",
+            "gemm": "bf16" if bf16_gemm else "split" if split_gemm else "fp32",
             "whole_step_algorithmic_hbm_frac": per_gpu_fps * step_bytes / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,

@@ -45,13 +45,16 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
 void wunet_destroy(wunet_ctx* ctx);
 
 /* GEMM arithmetic of the levels >= 32 samples.  enable = 1: forward convs, data gradients and weight
- * gradients run as fp16-split GEMMs - every fp32 operand x is carried as hi + lo in fp16 (22 significant bits,
- * gradients pre-scaled by a power of two), a product is three v_mfma_f32_16x16x32_f16 passes with fp32 accumulation -
+ * gradients run as fp16-split GEMMs - every fp32 operand x is carried as hi + lo in fp16 (22 significant bits; weights,
+ * activations and gradients each with a power-of-two scale derived on the device, so the result does not depend on the
+ * magnitude of the checkpoint), a product is three v_mfma_f32_16x16x32_f16 passes with fp32 accumulation -
  * wherever the position grid fills the chip (levels >= 256 samples; 128 .. 32 samples at >= 1024 positions per level,
  * with split-K); 2: wherever the kernels can run (>= 16 samples; small test shapes); 0: fp32 MFMA
- * (v_mfma_f32_16x16x4_f32) everywhere.  Accuracy of the split path is at the fp32 noise floor (DESIGN.md §7), but the
- * arithmetic is not bit-identical to the fp32 path.  A new ctx starts with 0; the Python Engine turns 1 on unless
- * WUNET_H3=0.  Changes the workspace size: call before wunet_workspace_bytes.  No reference counterpart. */
+ * (v_mfma_f32_16x16x4_f32) everywhere.  Accuracy of the split path is at the fp32 noise floor (DESIGN.md section 7), but the
+ * arithmetic is not bit-identical to the fp32 path.  3 / 4: the layer sets of 1 / 2 in the bf16 mode of the same kernels -
+ * operands stored as one bf16 word, one v_mfma_f32_16x16x32_bf16 pass, fp32 accumulation (BASELINE.json configs[4]; accuracy
+ * is that of bf16: ~1e-2, tests/test_bf16_mode.py).  A new ctx starts with 0; the Python Engine turns 1 on unless
+ * WUNET_H3 says otherwise.  Changes the workspace size: call before wunet_workspace_bytes.  No reference counterpart. */
 int wunet_set_h3(wunet_ctx* ctx, int enable);
 
 /* Bytes of device workspace the caller must provide to wunet_forward (with_backward=0: inference;

@@ -157,6 +157,29 @@ inline wunet_f4 wunet_mfma16h(wunet_h8 a, wunet_h8 b, wunet_f4 c)
     return c;
 }
 
+// v_mfma_f32_16x16x32_bf16 emulation (the words are bf16 bit patterns)
+inline wunet_f4 wunet_mfma16b(wunet_h8 a, wunet_h8 b, wunet_f4 c)
+{
+    emu::FiberState& f = emu::cur_fiber();
+    emu::BlockState& blk = emu::cur_block();
+    const int lane = f.tidx.x & 63, wave = f.tidx.x >> 6, par = f.op_parity;
+    f.op_parity ^= 1;
+    std::memcpy(&blk.wave_a8[wave][par][lane][0], a.v, 16);
+    std::memcpy(&blk.wave_b8[wave][par][lane][0], b.v, 16);
+    emu::wave_barrier();
+    const int col = lane & 15;
+    auto b2f = [](unsigned short h) { uint32_t x = (uint32_t)h << 16; float v; std::memcpy(&v, &x, 4); return v; };
+    for (int r = 0; r < 4; ++r) {
+        const int row = (lane >> 4) * 4 + r;
+        float d = c[r];
+        for (int q = 0; q < 4; ++q)
+            for (int e = 0; e < 8; ++e)
+                d += b2f(blk.wave_a8[wave][par][q * 16 + row][e]) * b2f(blk.wave_b8[wave][par][q * 16 + col][e]);
+        c[r] = d;
+    }
+    return c;
+}
+
 // ds_read_b64_tr_b16 x2 (semantics measured on gfx950, see wunet_dev.h)
 inline wunet_h8 wunet_ldtr8(const wunet_half* p0, const wunet_half* p1)
 {

@@ -659,3 +659,31 @@ def test_shard_loader_gathers_on_the_gpu(dev, tmp_path):
         assert ng == nc and torch.equal(mg.cpu(), mc) and torch.equal(cg.cpu(), cc)
         n += 1
     assert n == 3
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[4]: the deep variant (16 levels / 65536 samples) in the bf16 mode
+@pytest.mark.parametrize("n,ci,B,T,mode", [(16, 24, 2, 65536, 3), (12, 24, 4, 16384, 3), (3, 16, 3, 1024, 4)],
+                         ids=["deep16x65536", "12x16384", "forced-small"])
+def test_bf16_mode_vs_reference_under_autocast(pkg, dev, n, ci, B, T, mode):
+    """wunet_set_h3(ctx, 3): bf16 operands, one MFMA pass (tests/test_bf16_mode.py states the bar): against the reference's
+    fp32 ATen CPU run the error must not exceed what the reference's own bf16 arithmetic (its forward under
+    torch.autocast(bfloat16) on the CPU) shows against that run."""
+    noisy, clean = plan.golden_batch(B, T, 7)
+    sd = plan.golden_state(n, ci, 0)
+    tsd = torch_port.state_to_torch(sd, requires_grad=True)
+    o32 = torch_port.forward(tsd, torch.from_numpy(noisy), n, ci, True)
+    torch_port.loss_value("mse", torch.from_numpy(clean), o32).backward()
+    ref_out, ref_grads = o32.detach().numpy(), {k: v.grad.numpy() for k, v in tsd.items() if v.requires_grad}
+    asd = torch_port.state_to_torch(sd, requires_grad=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ao = torch_port.forward(asd, torch.from_numpy(noisy), n, ci, True)
+        al = torch_port.loss_value("mse", torch.from_numpy(clean), ao)
+    al.backward()
+    oe_ref, ge_ref = _errs(ao.detach().float().numpy(), {k: v.grad.numpy() for k, v in asd.items() if v.requires_grad}, ref_out, ref_grads)
+    out, grads = _step_with_state(pkg, dev, sd, n, ci, noisy, clean, mode)
+    oe, ge = _errs(out, grads, ref_out, ref_grads)
+    print(f"bf16 mode n={n} T={T}: out err {oe:.2e} (autocast reference {oe_ref:.2e}), worst grad rel-norm {ge:.2e} ({ge_ref:.2e})")
+    assert np.isfinite(out).all()
+    assert oe <= oe_ref and ge <= ge_ref, (oe, ge, oe_ref, ge_ref)
+    assert oe > 1e-4                       # really the bf16 arithmetic

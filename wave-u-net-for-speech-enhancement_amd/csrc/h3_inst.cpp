@@ -4,12 +4,17 @@
 
 #define WUNET_CASE(T, M, S)                                                                                \
     if (taps == T && mrep == M && nseg == S) {                                                             \
-        if (WUNET_ALLOW_BIG_LDS((conv_h3_kernel<T, M, S>), smem) != 0) return -2;                          \
-        WUNET_LAUNCH((conv_h3_kernel<T, M, S>), grid, dim3(WUNET_THREADS), smem, st, a);                   \
+        if (bf) {                                                                                          \
+            if (WUNET_ALLOW_BIG_LDS((conv_h3_kernel<T, M, S, true>), smem) != 0) return -2;                \
+            WUNET_LAUNCH((conv_h3_kernel<T, M, S, true>), grid, dim3(WUNET_THREADS), smem, st, a);         \
+        } else {                                                                                           \
+            if (WUNET_ALLOW_BIG_LDS((conv_h3_kernel<T, M, S>), smem) != 0) return -2;                      \
+            WUNET_LAUNCH((conv_h3_kernel<T, M, S>), grid, dim3(WUNET_THREADS), smem, st, a);               \
+        }                                                                                                  \
         return 0;                                                                                          \
     }
 
-int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st)
+int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf)
 {
     WUNET_CASE(15, 2, 1) WUNET_CASE(15, 3, 1) WUNET_CASE(15, 4, 1)
     WUNET_CASE(5, 2, 1) WUNET_CASE(5, 3, 1) WUNET_CASE(5, 4, 1)
@@ -35,14 +40,19 @@ int wunet_launch_conv_h3p(const ConvH3Args& a, int taps, int mrep, dim3 grid, si
 
 #define WUNET_WCASE(T, M, S, P)                                                                            \
     if (taps == T && mrep == M && nseg == S && tp == P) {                                                  \
-        if (WUNET_ALLOW_BIG_LDS((wgrad_h3_kernel<T, M, S, P>), smem) != 0) return -2;                      \
-        WUNET_LAUNCH((wgrad_h3_kernel<T, M, S, P>), grid, dim3(WUNET_THREADS), smem, st, a);               \
+        if (bf) {                                                                                          \
+            if (WUNET_ALLOW_BIG_LDS((wgrad_h3_kernel<T, M, S, P, true>), smem) != 0) return -2;            \
+            WUNET_LAUNCH((wgrad_h3_kernel<T, M, S, P, true>), grid, dim3(WUNET_THREADS), smem, st, a);     \
+        } else {                                                                                           \
+            if (WUNET_ALLOW_BIG_LDS((wgrad_h3_kernel<T, M, S, P>), smem) != 0) return -2;                  \
+            WUNET_LAUNCH((wgrad_h3_kernel<T, M, S, P>), grid, dim3(WUNET_THREADS), smem, st, a);           \
+        }                                                                                                  \
         return 0;                                                                                          \
     }
 #define WUNET_WCASES(T, M) WUNET_WCASE(T, M, 1, 128) WUNET_WCASE(T, M, 2, 128) WUNET_WCASE(T, M, 4, 128) WUNET_WCASE(T, M, 8, 128) \
                            WUNET_WCASE(T, M, 1, 256) WUNET_WCASE(T, M, 2, 256) WUNET_WCASE(T, M, 4, 256)
 
-int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st)
+int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st, bool bf)
 {
     WUNET_WCASES(15, 2) WUNET_WCASES(15, 3) WUNET_WCASES(15, 4) WUNET_WCASES(15, 5) WUNET_WCASES(15, 6)
     WUNET_WCASES(5, 2) WUNET_WCASES(5, 3) WUNET_WCASES(5, 4) WUNET_WCASES(5, 5) WUNET_WCASES(5, 6)
@@ -51,12 +61,17 @@ int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, in
 
 #define WUNET_DCASE(T, M, D)                                                                               \
     if (taps == T && mrep == M && db == D) {                                                               \
-        if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M, D>), smem) != 0) return -2;                        \
-        WUNET_LAUNCH((wgrad_h3d_kernel<T, M, D>), grid, dim3(WUNET_THREADS), smem, st, a);                 \
+        if (bf) {                                                                                          \
+            if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M, D, true>), smem) != 0) return -2;              \
+            WUNET_LAUNCH((wgrad_h3d_kernel<T, M, D, true>), grid, dim3(WUNET_THREADS), smem, st, a);       \
+        } else {                                                                                           \
+            if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M, D>), smem) != 0) return -2;                    \
+            WUNET_LAUNCH((wgrad_h3d_kernel<T, M, D>), grid, dim3(WUNET_THREADS), smem, st, a);             \
+        }                                                                                                  \
         return 0;                                                                                          \
     }
 
-int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st)
+int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st, bool bf)
 {
     WUNET_DCASE(15, 2, true) WUNET_DCASE(15, 3, true) WUNET_DCASE(15, 4, true) WUNET_DCASE(15, 5, true) WUNET_DCASE(15, 6, true)
     WUNET_DCASE(5, 2, true) WUNET_DCASE(5, 3, true) WUNET_DCASE(5, 4, true) WUNET_DCASE(5, 5, true)

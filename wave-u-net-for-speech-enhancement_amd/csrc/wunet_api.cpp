@@ -295,6 +295,7 @@ struct wunet_ctx {
     size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, hpart2_off, total_floats;
     int head_blocks;
     int h3 = 0;                   // fp16-split GEMMs: 0 off, 1 where the planner wants them, 2 wherever they can run
+    int bf = 0;                   // the split kernels run their bf16 mode (one bf16 word per operand value, one MFMA pass)
     size_t h3_wf_hi, h3_wf_lo, h3_wb_hi, h3_wb_lo, h3_slot;   // float offsets
     size_t fslot_off, wmax_off;   // forward segment: WUNET_SLOT_FLOATS per layer (x / weight scales, activation bound), partial max |W|
     size_t h3_wf_halfs, h3_wb_halfs;
@@ -546,13 +547,13 @@ void layout_workspace(wunet_ctx* c)
 
 // ---- fp16-split helpers
 int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc, const float* xb0, const float* xb1, float* xsc,
-                 int B, int C, int L, hipStream_t st)
+                 int B, int C, int L, hipStream_t st, int bf = 0)
 {
     const int c8 = (C + 7) / 8;
     const size_t n = (size_t)B * c8 * (L / 4);
     size_t blocks = (n + WUNET_THREADS - 1) / WUNET_THREADS;
     if (blocks > 16384) blocks = 16384;
-    WUNET_LAUNCH(split_act_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, hi, lo, sc, xb0, xb1, xsc, B, C, c8, L, ilog2(L));
+    WUNET_LAUNCH(split_act_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, hi, lo, sc, xb0, xb1, xsc, B, C, c8, L, ilog2(L), bf);
     return 0;
 }
 
@@ -570,7 +571,8 @@ bool h3_conv_is_paired(int B, int L)
 
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
-                   int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr)
+                   int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr,
+                   int bf = 0)
 {
     char pname[96];
     const double posn = (double)B * L;
@@ -584,7 +586,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     // paired tiles (conv_h3p_kernel: two tiles per 512-thread block, double-buffered shared W) for L >= 256 with an even tile count
-    const bool paired = h3_conv_is_paired(B, L);            // (A/B switch: WUNET_H3_PAIR=0)
+    const bool paired = !bf && h3_conv_is_paired(B, L);     // (A/B switch: WUNET_H3_PAIR=1)
     int rc;
     if (paired) {
         snprintf(pname, sizeof pname, "conv_h3p_kernel<%d, %d>", taps, mrep);
@@ -593,11 +595,12 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
         const dim3 grid((unsigned)((a.ntiles / 2) * a.mblocks), (unsigned)ksplit);
         rc = wunet_launch_conv_h3p(a, taps, mrep, grid, smem, st);
     } else {
-        snprintf(pname, sizeof pname, "conv_h3_kernel<%d, %d, %d>", taps, mrep, nseg);
-        prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
-        const size_t smem = (size_t)(2 * 4 * nseg * (256 / nseg + 16) + 2 * mrep * 5 * 64) * 16;
+        snprintf(pname, sizeof pname, bf ? "conv_h3_kernel<%d, %d, %d, bf16>" : "conv_h3_kernel<%d, %d, %d>", taps, mrep, nseg);
+        prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)));
+        const int npl = bf ? 1 : 2;
+        const size_t smem = (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16;
         const dim3 grid((unsigned)(a.ntiles * a.mblocks), (unsigned)ksplit);
-        rc = wunet_launch_conv_h3(a, taps, mrep, nseg, grid, smem, st);
+        rc = wunet_launch_conv_h3(a, taps, mrep, nseg, grid, smem, st, bf != 0);
     }
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d nseg=%d (rc %d)", taps, mrep, nseg, rc);
@@ -605,7 +608,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
 }
 
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
-                    const float* sc, const float* sc2, const float* zero, float* part, int B, hipStream_t st)
+                    const float* sc, const float* sc2, const float* zero, float* part, int B, hipStream_t st, int bf = 0)
 {
     char pname[96];
     const double posn = (double)B * l.L;
@@ -614,7 +617,8 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     // DMA-staged, double-buffered variant: whole chunks inside one item (L >= 128), both buffers within the 160 KB
     // (blocks of two m-tiles keep the register-staged kernel: it runs two blocks per CU, which is worth more)
     static const bool dma = getenv("WUNET_NO_H3W_DMA") == nullptr;                // A/B switch
-    const size_t smem_d = (size_t)2 * (2 * (l.h3w_mrep * 2) * 132 + 2 * xg * 148 + 8) * 16;
+    const int npl = bf ? 1 : 2;
+    const size_t smem_d = (size_t)2 * (npl * (l.h3w_mrep * 2) * 132 + npl * xg * 148 + 8) * 16;
     int rc;
     if (dma && nseg == 1 && tp == 128 && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
         WgradH3dArgs a{};
@@ -622,23 +626,23 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
         a.zero = reinterpret_cast<const wunet_half*>(zero);
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
-        snprintf(pname, sizeof pname, "wgrad_h3d_kernel<%d, %d>", l.taps, l.h3w_mrep);
+        snprintf(pname, sizeof pname, bf ? "wgrad_h3d_kernel<%d, %d, bf16>" : "wgrad_h3d_kernel<%d, %d>", l.taps, l.h3w_mrep);
         prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
         // two blocks per CU with a single buffer where the registers allow it (two independent blocks hide each other's
         // waits: +18-28 % on those kernels), else one block with double-buffered tiles
         static const bool sb = getenv("WUNET_NO_H3W_SB") == nullptr;              // A/B switch
         const bool db = !(sb && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3)));
-        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st);
+        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st, bf != 0);
     } else {
         WgradH3Args a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
-        snprintf(pname, sizeof pname, "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
+        snprintf(pname, sizeof pname, bf ? "wgrad_h3_kernel<%d, %d, bf16>" : "wgrad_h3_kernel<%d, %d>", l.taps, l.h3w_mrep);
         prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
         const int xrows = nseg == 1 ? tp + 20 : nseg * (tp / nseg + 16), xpos = ((xrows + 11) / 16) * 16 + 4;
-        const size_t smem = ((size_t)2 * (l.h3w_mrep * 2) * (tp + 4) + (size_t)2 * xg * xpos + 8) * 16;
-        rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, tp, grid, smem, st);
+        const size_t smem = ((size_t)npl * (l.h3w_mrep * 2) * (tp + 4) + (size_t)npl * xg * xpos + 8) * 16;
+        rc = wunet_launch_wgrad_h3(a, l.taps, l.h3w_mrep, nseg, tp, grid, smem, st, bf != 0);
     }
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no wgrad_h3 kernel for taps=%d mrep=%d (rc %d)", l.taps, l.h3w_mrep, rc);
@@ -705,7 +709,9 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
 int wunet_set_h3(wunet_ctx* ctx, int enable)
 {
     if (!ctx) return fail(WUNET_E_ARG, "null ctx");
-    ctx->h3 = enable == 2 ? 2 : (enable ? 1 : 0);
+    // 3 / 4: the planner's (3) or the forced (4) layer set on the bf16 mode of the same kernels
+    ctx->bf = (enable == 3 || enable == 4) ? 1 : 0;
+    ctx->h3 = (enable == 2 || enable == 4) ? 2 : (enable ? 1 : 0);
     layout_workspace(ctx);          // sizes and offsets change: call before wunet_workspace_bytes
     return WUNET_OK;
 }
@@ -795,6 +801,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             d.w = params[4 * i]; d.hi = wh + l.h3f_wpk; d.lo = wl + l.h3f_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cout; d.kch = l.cin; d.mtiles = l.h3f_mtp; d.nch = l.h3f_nch; d.transposed = 0;
             d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i; d.wsc = ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
+            d.bf = c->bf;
         }
         if (nd > 0) {
             WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
@@ -825,6 +832,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 ph.xb0 = fslot + (size_t)WUNET_SLOT_FLOATS * l.src0 + 4;
                 ph.xb1 = l.kind == LK_UPCAT ? fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4 : nullptr;
                 ph.xsc = fslot + (size_t)WUNET_SLOT_FLOATS * i;
+                ph.bf = c->bf;
                 if (l.kind == LK_DECIM && training) {
                     const int dj = 2 * c->n - i + 1;             // the decoder layer that concatenates this pass's producer
                     if (dj < c->NL && c->ly[dj].skip_from == i) {
@@ -907,14 +915,14 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             float* const sl = fslot + (size_t)WUNET_SLOT_FLOATS * i;      // [0..1] x scale, [2..3] weight scale
             if (!l.h3x) {
                 launch_split(xin, xh, xl, nullptr, fslot + (size_t)WUNET_SLOT_FLOATS * l.src0 + 4,
-                             l.kind == LK_UPCAT ? fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4 : nullptr, sl, c->B, l.cin, l.L, st);
+                             l.kind == LK_UPCAT ? fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4 : nullptr, sl, c->B, l.cin, l.L, st, c->bf);
                 WUNET_CHECK_LAUNCH();
             }
             int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, l.h3f_sps, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
-                                    l.cin, l.h3f_nch, l.L, st, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr);
+                                    l.cin, l.h3f_nch, l.L, st, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf);
             if (rc) return rc;
         } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;
@@ -931,7 +939,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         // 2c. BatchNorm statistics -> scale/shift for the consumers (+ running stats)
         if (ev_epi) {
             int nrows = l.first ? l.f.grid_x : (int)(((long long)c->B * l.L + 255) / 256) * (l.h3f_mtp / l.h3f_mrep);
-            if (!l.first && h3_conv_is_paired(c->B, l.L)) nrows /= 2;            // conv_h3p_kernel: one row per tile pair
+            if (!l.first && !c->bf && h3_conv_is_paired(c->B, l.L)) nrows /= 2;            // conv_h3p_kernel: one row per tile pair
             WUNET_LAUNCH(xb_reduce_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, (const float*)xrows, nrows, fslot + (size_t)WUNET_SLOT_FLOATS * i + 4);
         } else if (split) {
             // sum the z-slices (+bias -> z) and reduce the BN statistics; short levels finish BN in the same launch
@@ -1023,6 +1031,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                 d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
                 d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i;      // the forward's maxima: the weights have not changed since
                 d.wsc = l.h3f ? nullptr : ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
+                d.bf = c->bf;
             }
             if (n3 > 0) {
                 WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), n3), dim3(WUNET_THREADS), 0, st, t3);
@@ -1103,7 +1112,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                  (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
                                  ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                 c->B, l.cout, c8, l.L, l.logL);
+                                 c->B, l.cout, c8, l.L, l.logL, c->bf);
                 } else if (tiny)
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
                                  (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
@@ -1133,7 +1142,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     rc = launch_wgrad_h3(l, reinterpret_cast<const wunet_half*>(ws + l.xh), reinterpret_cast<const wunet_half*>(ws + l.xl),
                                          reinterpret_cast<const wunet_half*>(ws + l.gzh), reinterpret_cast<const wunet_half*>(ws + l.gzl),
                                          ws + c->h3_slot + 8 + 4 * i, ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i, ws + c->h3_slot,
-                                         ws + c->wgpart_off, c->B, sd);
+                                         ws + c->wgpart_off, c->B, sd, c->bf);
                 else {
                     const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
                     rc = launch_wgrad_any(l.taps, w, l.w, sd);
@@ -1180,7 +1189,8 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
                                     ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2,
-                                    split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st);
+                                    split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st, nullptr, nullptr,
+                                    nullptr, c->bf);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
             if (split) {

@@ -49,6 +49,13 @@ __device__ __forceinline__ wunet_f4 wunet_mfma16h(wunet_h8 a, wunet_h8 b, wunet_
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// v_mfma_f32_16x16x32_bf16, same lane layout: the bf16 mode (one pass on bf16 operands, BASELINE configs[4]) - the 16-bit words
+// of a wunet_h8 are then bf16 bit patterns
+__device__ __forceinline__ wunet_f4 wunet_mfma16b(wunet_h8 a, wunet_h8 b, wunet_f4 c)
+{
+    typedef __bf16 wunet_b8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wunet_b8, a), __builtin_bit_cast(wunet_b8, b), c, 0, 0, 0);
+}
 // Transposed LDS read (ds_read_b64_tr_b16), twice: within each 16-lane group the lanes' 8-byte pieces form a
 // [4 rows][16 columns] half matrix (row j = lanes 4j..4j+3, 4 columns each) and lane i receives column i.  Measured on
 // gfx950: out[lane i][j] = in[lane 4j + (i >> 2)].half[i & 3].  p0 feeds halfs 0-3 of the result, p1 halfs 4-7: an MFMA
@@ -99,6 +106,22 @@ __device__ __forceinline__ void wunet_split_h(float x, wunet_half& hi, wunet_hal
 {
     hi = wunet_f2h(x);
     lo = wunet_f2h(x - wunet_h2f(hi));
+}
+
+// fp32 -> bf16 bits, round to nearest even (NaN stays NaN); written out so that the GPU and the test emulator agree bit for bit
+__device__ __forceinline__ wunet_half wunet_f2b(float x)
+{
+    unsigned u = wunet_fbits(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (wunet_half)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (wunet_half)(u >> 16);
+}
+// operand conversion of the GEMM paths: fp16 hi/lo split, or (BF) one bf16 word (lo unused)
+template <bool BF>
+__device__ __forceinline__ void wunet_split(float x, wunet_half& hi, wunet_half& lo)
+{
+    if (BF) { hi = wunet_f2b(x); lo = 0; }
+    else wunet_split_h(x, hi, lo);
 }
 
 // Power-of-two scale 2^k with 2^k * bound in [2^T, 2^(T+1)) - multiplying by it is exact, so the split operands keep their 22 bits

@@ -38,7 +38,9 @@ struct ConvH3Args {
     size_t split_stride;                          // floats between the partial results of two splits
 };
 
-template <int TAPS, int M_REP, int NSEG>
+// BF: the bf16 mode - the operand arrays hold ONE bf16 word per value (xl / wl unused), a product is one pass of
+// v_mfma_f32_16x16x32_bf16; the LDS tiles and the staging traffic halve.
+template <int TAPS, int M_REP, int NSEG, bool BF = false>
 __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
 {
     constexpr int PAD = TAPS / 2;
@@ -46,10 +48,11 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
     constexpr int NTG = TAPS / TG;
     constexpr int LSEG = 256 / NSEG, SW = LSEG + 16;      // samples per segment, its columns incl. the halo of 8 + 8
     constexpr int COLS = NSEG * SW;               // 272 / 288 / 320
-    constexpr int XP = 2 * 4 * COLS;              // 16-byte pieces of the x tile (hi + lo)
+    constexpr int NPL = BF ? 1 : 2;               // operand planes: hi (+ lo)
+    constexpr int XP = NPL * 4 * COLS;            // 16-byte pieces of the x tile (hi + lo)
     constexpr int XIT = (XP + WUNET_THREADS - 1) / WUNET_THREADS;     // 9
     constexpr int WPM = TG * 64;                  // pieces per (m-tile, hi|lo) sub-tile
-    constexpr int WP = 2 * M_REP * WPM;
+    constexpr int WP = NPL * M_REP * WPM;
     constexpr int WIT = (WP + WUNET_THREADS - 1) / WUNET_THREADS;
     WUNET_DYN_SMEM(smem);
     wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS][8]
@@ -160,40 +163,26 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
             const int ec = tg * TG + e + 8 - PAD;                 // column = 4 * (wave*16 + i16) + ec
             const int po = ((ec & 3) * (COLS / 4) + (ec >> 2)) * 8;
             fh[e] = wunet_ldh8(xs + boff + po);
-            fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
+            if (!BF) fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
         }
-#ifndef WUNET_ABL
-#define WUNET_ABL 0
-#endif
-#if WUNET_ABL == 1 || WUNET_ABL == 4          // measurement builds only (wrong results): A fragments read once per stage
-        wunet_h8 ah[M_REP], al[M_REP];
-#pragma unroll
-        for (int mt = 0; mt < M_REP; ++mt) {
-            ah[mt] = wunet_ldh8(ws + ((mt * TG) * 64) * 8 + aoff);
-            al[mt] = wunet_ldh8(ws + ((M_REP + mt) * TG) * 64 * 8 + aoff);
-        }
-#endif
 #pragma unroll
         for (int tl = 0; tl < TG; ++tl) {
-#if !(WUNET_ABL == 1 || WUNET_ABL == 4)
             wunet_h8 ah[M_REP], al[M_REP];
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt) {
                 ah[mt] = wunet_ldh8(ws + ((mt * TG + tl) * 64) * 8 + aoff);
-                al[mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + tl) * 64 * 8 + aoff);
+                if (!BF) al[mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + tl) * 64 * 8 + aoff);
             }
-#endif
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-#if WUNET_ABL == 3 || WUNET_ABL == 4          // measurement builds only: no matrix instructions, operands kept alive by one VALU op each
-                    acc[mt][nt][0] += (float)al[mt][0] * (float)fh[tl + nt][1] + (float)ah[mt][2] * (float)fl[tl + nt][3];
-#else
-                    acc[mt][nt] = wunet_mfma16h(al[mt], fh[tl + nt], acc[mt][nt]);
-                    acc[mt][nt] = wunet_mfma16h(ah[mt], fl[tl + nt], acc[mt][nt]);
-                    acc[mt][nt] = wunet_mfma16h(ah[mt], fh[tl + nt], acc[mt][nt]);
-#endif
+                    if (BF) acc[mt][nt] = wunet_mfma16b(ah[mt], fh[tl + nt], acc[mt][nt]);
+                    else {
+                        acc[mt][nt] = wunet_mfma16h(al[mt], fh[tl + nt], acc[mt][nt]);
+                        acc[mt][nt] = wunet_mfma16h(ah[mt], fl[tl + nt], acc[mt][nt]);
+                        acc[mt][nt] = wunet_mfma16h(ah[mt], fh[tl + nt], acc[mt][nt]);
+                    }
                 }
         }
     }
@@ -533,7 +522,7 @@ struct WgradH3Args {
     size_t part_stride;                           // floats between two splits' partial results
 };
 
-template <int TAPS, int M_REP, int NSEG, int TP>
+template <int TAPS, int M_REP, int NSEG, int TP, bool BF = false>
 __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_kernel(WgradH3Args A)
 {
     constexpr int GP = TP + 4;                      // TP positions per chunk; plane stride (pieces) of the g_z image, 4 mod 16
@@ -544,13 +533,14 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
     constexpr int TW = TAPS == 15 ? 8 : 5;          // taps per wave
     constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;    // funnel offset of the wave's first tap
     constexpr int CIB = WG * 16, XG = CIB / 8, GG = M_REP * 2;
-    constexpr int GPC = 2 * GG * TP;                // pieces staged per chunk: g_z, x
-    constexpr int XPC = 2 * XG * XROWS;
-    constexpr int GIT = GPC / WUNET_THREADS;        // 2 * M_REP
+    constexpr int NPL = BF ? 1 : 2;                 // operand planes: hi (+ lo); BF: one bf16 word per value
+    constexpr int GPC = NPL * GG * TP;              // pieces staged per chunk: g_z, x
+    constexpr int XPC = NPL * XG * XROWS;
+    constexpr int GIT = (GPC + WUNET_THREADS - 1) / WUNET_THREADS;
     constexpr int XIT = (XPC + WUNET_THREADS - 1) / WUNET_THREADS;
     WUNET_DYN_SMEM(smem);
     wunet_half* gs = reinterpret_cast<wunet_half*>(smem);                      // [hi|lo][GG][GP][8]
-    wunet_half* xs = gs + 2 * GG * GP * 8;                                     // [hi|lo][XG][XPOS][8] (+ slack behind it)
+    wunet_half* xs = gs + NPL * GG * GP * 8;                                     // [hi|lo][XG][XPOS][8] (+ slack behind it)
     static_assert(XROWS <= XPOS, "x image");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
@@ -586,7 +576,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
             const int pl_ = f_ / TP, pos_ = f_ - pl_ * TP;                 /* plane = which * GG + group */       \
             const int c8_ = (co0 >> 3) + (pl_ % GG);                                                              \
             const int p_ = l0_ + pos_;                                     /* L = 64: the second item of the chunk */ \
-            const bool ok_ = c8_ < A.GC8 && b_ + (p_ >> A.logL) < A.B;                                            \
+            const bool ok_ = f_ < GPC && c8_ < A.GC8 && b_ + (p_ >> A.logL) < A.B;                               \
             const wunet_half* src_ = pl_ >= GG ? A.gl : A.gh;                                                     \
             greg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)(b_ + (p_ >> A.logL)) * A.GC8 + c8_) * L + (p_ & (L - 1))) * 8 : 0)); \
         }                                                                                                         \
@@ -611,7 +601,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
             const int f = tid + it * WUNET_THREADS;
             const int pl = f / TP, pos = f - pl * TP;
             const bool ok = (co0 >> 3) + (pl % GG) < A.GC8 && (int)((k * TP + pos) >> A.logL) < A.B;
-            wunet_sth8(gs + ((size_t)pl * GP + pos) * 8, wunet_selh8(ok, greg[it]));
+            if (f < GPC) wunet_sth8(gs + ((size_t)pl * GP + pos) * 8, wunet_selh8(ok, greg[it]));
         }
 #pragma unroll
         for (int it = 0; it < XIT; ++it) {
@@ -632,7 +622,7 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
             for (int mt = 0; mt < M_REP; ++mt) {
                 const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
                 ah[mt] = wunet_ldtr8(p, p + 32);
-                al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
+                if (!BF) al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
             }
             // the tap shift is a row offset of the transposed read (rows are 16-byte pieces: any alignment)
 #pragma unroll
@@ -641,12 +631,16 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
                     const int krow = ((ks * 32) / LSEG) * SWX + (ks * 32) % LSEG;                   // first x row of this K step
                     const wunet_half* p = xs + xbase + (krow + OB + tw) * 8;
                     const wunet_h8 bh = wunet_ldtr8(p, p + 32);
-                    const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
+                    wunet_h8 bl = bh;
+                    if (!BF) bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
 #pragma unroll
                     for (int mt = 0; mt < M_REP; ++mt) {
-                        acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
-                        acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
-                        acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
+                        if (BF) acc[mt][tw] = wunet_mfma16b(ah[mt], bh, acc[mt][tw]);
+                        else {
+                            acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
+                            acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
+                            acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
+                        }
                     }
                 }
             }
@@ -688,7 +682,7 @@ struct WgradH3dArgs {
     size_t part_stride;
 };
 
-template <int TAPS, int M_REP, bool DB>
+template <int TAPS, int M_REP, bool DB, bool BF = false>
 __global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(WgradH3dArgs A)
 {
     constexpr int TP = 128, GP = TP + 4, XPOS = TP + 20;          // plane strides (pieces), both 4 mod 16
@@ -696,8 +690,9 @@ __global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(
     constexpr int TW = TAPS == 15 ? 8 : 5;
     constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;
     constexpr int CIB = WG * 16, XG = CIB / 8, GG = M_REP * 2;
-    constexpr int GPCS = 2 * GG * GP;               // pieces of the g_z image (rows 128..131 of a plane are never read or written)
-    constexpr int XPCS = 2 * XG * XPOS;             // pieces of the x image
+    constexpr int NPL = BF ? 1 : 2;                 // operand planes: hi (+ lo); BF: one bf16 word per value
+    constexpr int GPCS = NPL * GG * GP;             // pieces of the g_z image (rows 128..131 of a plane are never read or written)
+    constexpr int XPCS = NPL * XG * XPOS;           // pieces of the x image
     constexpr int GIT = (GPCS + WUNET_THREADS - 1) / WUNET_THREADS;
     constexpr int XIT = (XPCS + WUNET_THREADS - 1) / WUNET_THREADS;
     constexpr int BUF = (GPCS + XPCS + 8) * 8;      // halfs per buffer (+ slack behind the x image)
@@ -787,18 +782,22 @@ __global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(
             for (int mt = 0; mt < M_REP; ++mt) {
                 const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
                 ah[mt] = wunet_ldtr8(p, p + 32);
-                al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
+                if (!BF) al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
             }
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
                 const wunet_half* p = gs + xbase + (ks * 32 + OB + tw) * 8;
                 const wunet_h8 bh = wunet_ldtr8(p, p + 32);
-                const wunet_h8 bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
+                wunet_h8 bl = bh;
+                if (!BF) bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
 #pragma unroll
                 for (int mt = 0; mt < M_REP; ++mt) {
-                    acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
-                    acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
-                    acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
+                    if (BF) acc[mt][tw] = wunet_mfma16b(ah[mt], bh, acc[mt][tw]);
+                    else {
+                        acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
+                        acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
+                        acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
+                    }
                 }
             }
         }

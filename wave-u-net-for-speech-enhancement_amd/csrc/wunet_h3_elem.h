@@ -83,6 +83,13 @@ __global__ __launch_bounds__(WUNET_THREADS) void act_max_kernel(const float* z, 
     }
 }
 
+// runtime form of wunet_split<BF> for the elementwise producers (bf: the bf16 mode, one word per value, lo array unused)
+__device__ __forceinline__ void wunet_split_rt(int bf, float x, wunet_half& hi, wunet_half& lo)
+{
+    if (bf) { hi = wunet_f2b(x); lo = 0; }
+    else wunet_split_h(x, hi, lo);
+}
+
 // x scale of a conv input whose sources' activation bounds are xb0 (and xb1): every thread derives the same value
 __device__ __forceinline__ void wunet_x_scale(const float* xb0, const float* xb1, float& s, float& inv)
 {
@@ -93,7 +100,7 @@ __device__ __forceinline__ void wunet_x_scale(const float* xb0, const float* xb1
 // (channel group, 4 samples): 8 float4 loads, 4+4 16-byte stores.
 __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x, wunet_half* hi, wunet_half* lo, const float* sc,
                                                                    const float* xb0, const float* xb1, float* xsc,
-                                                                   int B, int C, int C8, int L, int logL)
+                                                                   int B, int C, int C8, int L, int logL, int bf)
 {
     const int l4n = L >> 2;
     float s = sc ? sc[0] : 1.0f;
@@ -122,12 +129,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 wunet_half a, d;
-                wunet_split_h(s * v[e][j], a, d);
+                wunet_split_rt(bf, s * v[e][j], a, d);
                 wunet_put_half(h, e, a);
                 wunet_put_half(l, e, d);
             }
             wunet_sth8(ph + 8 * j, h);
-            wunet_sth8(pl + 8 * j, l);
+            if (!bf) wunet_sth8(pl + 8 * j, l);
         }
     }
 }
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3R
 // block 0 publishes {scale, 1/scale} for the GEMMs.  One thread per (channel group, 4 samples).
 __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                      const float* k3, const float* bound, float* sc, wunet_half* hi,
-                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL)
+                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int bf)
 {
     __shared__ float red[WUNET_THREADS];
     float m = 0.0f;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     wunet_half x, y;
-                    wunet_split_h(v[e][j], x, y);
+                    wunet_split_rt(bf, v[e][j], x, y);
                     wunet_put_half(h, e, x);
                     wunet_put_half(l, e, y);
                 }
@@ -301,7 +308,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
             if (src < total) {
                 const size_t o = (4 * (base + wbase) + piece) * 8;
                 wunet_sth8(hi + o, tb[0][wbase * 4 + piece]);
-                wunet_sth8(lo + o, tb[1][wbase * 4 + piece]);
+                if (!bf) wunet_sth8(lo + o, tb[1][wbase * 4 + piece]);
             }
         }
         __syncthreads();
@@ -327,6 +334,7 @@ struct PrepH3Args {
     // writes (its own pass derives and publishes the same scale)
     const float* xb0; const float* xb1; float* xsc;
     const float* ssb0; const float* ssb1;
+    int bf;              // bf16 mode: one bf16 word per value into xh / sh, the lo arrays are not written
 };
 
 // One thread = 8 channels of ONE sample, consecutive lanes = consecutive samples: every store instruction of a wave
@@ -375,12 +383,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                     }
                 }
                 wunet_half a, d;
-                wunet_split_h(xs_ * v, a, d);
+                wunet_split_rt(A.bf, xs_ * v, a, d);
                 wunet_put_half(h, e, a);
                 wunet_put_half(l, e, d);
             }
             wunet_sth8(A.xh + (row * A.L + (size_t)p) * 8, h);
-            wunet_sth8(A.xl + (row * A.L + (size_t)p) * 8, l);
+            if (!A.bf) wunet_sth8(A.xl + (row * A.L + (size_t)p) * 8, l);
         }
         if (SKIP_DST) {
             // skip half of the decoder input at the producer's resolution: the wave's 64 samples p0 .. p0+63 come from the
@@ -399,12 +407,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                     const int c = c8 * 8 + e;
                     const float v = c < C ? wunet_lrelu(A.a0[c] * A.z0[((size_t)b * A.C0 + c) * (size_t)(2 * A.L) + q] + A.s0[c]) : 0.0f;
                     wunet_half a, d;
-                    wunet_split_h(ss_ * v, a, d);
+                    wunet_split_rt(A.bf, ss_ * v, a, d);
                     wunet_put_half(h, e, a);
                     wunet_put_half(l, e, d);
                 }
                 wunet_sth8(A.sh + (srow * (size_t)(2 * A.L) + (size_t)q) * 8, h);
-                wunet_sth8(A.sl + (srow * (size_t)(2 * A.L) + (size_t)q) * 8, l);
+                if (!A.bf) wunet_sth8(A.sl + (srow * (size_t)(2 * A.L) + (size_t)q) * 8, l);
             }
         }
     }
@@ -487,12 +495,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 wunet_half a, d;
-                wunet_split_h(xs_ * v[e][j], a, d);
+                wunet_split_rt(A.bf, xs_ * v[e][j], a, d);
                 wunet_put_half(h, e, a);
                 wunet_put_half(l, e, d);
             }
             wunet_sth8(ph + 8 * j, h);
-            wunet_sth8(pl + 8 * j, l);
+            if (!A.bf) wunet_sth8(pl + 8 * j, l);
         }
         if (A.kind == 0 && A.sh) {
             // skip half of the decoder input at the producer's resolution (2L): samples 8*l4 .. 8*l4+7 = even/odd interleaved
@@ -505,12 +513,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     wunet_half a, d;
-                    wunet_split_h(ss_ * ((j & 1) ? vo[e][j >> 1] : v[e][j >> 1]), a, d);
+                    wunet_split_rt(A.bf, ss_ * ((j & 1) ? vo[e][j >> 1] : v[e][j >> 1]), a, d);
                     wunet_put_half(h, e, a);
                     wunet_put_half(l, e, d);
                 }
                 wunet_sth8(qh + 8 * j, h);
-                wunet_sth8(ql + 8 * j, l);
+                if (!A.bf) wunet_sth8(ql + 8 * j, l);
             }
         }
     }
@@ -529,6 +537,7 @@ struct PackH3Desc {
     int transposed;
     const float* wmax;     // WUNET_WMAX_PARTS partial maxima of |w| (h3_scales_kernel)
     float* wsc;            // {scale, 1/scale} of the packed weights, published by block 0 (nullptr: another pack of this layer did)
+    int bf;                // bf16 mode: one bf16 word per weight into hi
 };
 struct PackH3Table { PackH3Desc d[WUNET_MAX_CONV_LAYERS]; };
 
@@ -561,9 +570,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
         if (row < d.rows && k < d.kch)
             v = d.transposed ? d.w[((size_t)k * d.Cin + row) * d.taps + (d.taps - 1 - t)] : d.w[((size_t)row * d.Cin + k) * d.taps + t];
         wunet_half a, b;
-        wunet_split_h(wscale * v, a, b);
+        wunet_split_rt(d.bf, wscale * v, a, b);
         d.hi[idx] = a;
-        d.lo[idx] = b;
+        if (!d.bf) d.lo[idx] = b;
     }
 }
 
