@@ -53,6 +53,47 @@ def net_flops_bytes(n, ci, frame):
     return fl, by
 
 
+def source_hash():
+    """sha1 over the kernel + host sources: measurements stored under profiles/ are stamped with it and refused when stale."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, PKG, "csrc", "*.h")) + glob.glob(os.path.join(ROOT, PKG, "csrc", "*.cpp")) +
+                   glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_traffic():
+    """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench): profiles/pmc_traffic.json,
+    produced by tools/measure_round.sh + tools/collect_round.py, stamped with the source hash of the build it was measured on."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        pmc = json.load(open(path))
+    except (OSError, ValueError):
+        return {"kernels": None, "why": "profiles/pmc_traffic.json missing"}
+    if pmc.get("source_hash") != source_hash():
+        return {"kernels": None, "why": f"profiles/pmc_traffic.json is stale (measured on sources {pmc.get('source_hash')}, these are "
+                                        f"{source_hash()}): refused"}
+    pmc["why"] = ("profiles/pmc_traffic.json (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, FETCH "
+                  "doubled per the gfx950 note of MI355X_MICROARCH.md; measured on these sources)")
+    return pmc
+
+
+def timed(fn, warmup, steps, batch, what):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"what": what, "ms_per_step": dt * 1e3, "frames_per_s": batch / dt, "steps": steps}
+
+
 def synthetic_batch(batch, device, seed, frame=FRAME):
     g = torch.Generator().manual_seed(seed)
     clean = torch.rand(batch, 1, frame, generator=g) * 2 - 1
@@ -122,9 +163,10 @@ def main():
                     help="replay the training step as ONE captured hipGraph (torch.cuda.CUDAGraph over forward + loss + backward + "
                          "fused Adam with its device-side step counter; SURVEY.md section 8 f2).  auto = off: measured on MI355X / "
                          "ROCm 7.0 the replay of the ~270-node graph costs the host as much as the eager launches (4.9 ms) and the "
-                         "GPU 4 % more (6.65 vs 6.41 ms per step), so the headline stays eager")
+                         "GPU 4 %% more (6.65 vs 6.41 ms per step), so the headline stays eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and eval-forward side measurements")
     args = ap.parse_args()
 
     if args.gemm is not None:
@@ -253,34 +295,75 @@ def main():
             name, n, ms, fl, by = line.split("\t")
             rows.append({"kernel": name, "launches": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
         rows.sort(key=lambda r: -r["ms"])
-        if rows:
-            top = rows[0]
+        gemm_rows = [r for r in rows if r["flops"] > 0 and ("mfma" in r["kernel"] or "_h3" in r["kernel"])]
+        mem_rows = [r for r in rows if r not in gemm_rows]
+        if gemm_rows:
+            top = gemm_rows[0]
             avg_ms = top["ms"] / top["launches"]
             achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
-            mfma_ms = sum(r["ms"] for r in rows) / nprof
-            # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            traffic, traffic_src = None, None
-            try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-                if top["kernel"] in pmc["kernels"]:
-                    traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
-                    traffic_src = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, FETCH doubled per the gfx950 note)"
-            except (OSError, ValueError, KeyError):
-                pass
+            mfma_ms = sum(r["ms"] for r in gemm_rows) / nprof
+            pmc = load_pmc_traffic()
+            traffic, traffic_src = None, pmc["why"]
+            if pmc["kernels"] is not None and top["kernel"] in pmc["kernels"]:
+                traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
             is_split = "_h3" in top["kernel"]
             is_bf = "bf16" in top["kernel"]
             peak = PEAK_F16_MFMA_TFLOPS if is_bf else PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
+            # the HBM-bound kernels of the shallow levels (north_star: "rocprof-reported HBM GB/s for the memory-bound shallow
+            # levels"): algorithmic bytes / HIP-event time, same pass
+            groups = {}
+            for r in mem_rows:
+                key = r["kernel"].split("<")[0]
+                g = groups.setdefault(key, {"kernel": key, "ms": 0.0, "bytes": 0.0, "launches": 0})
+                g["ms"] += r["ms"]; g["bytes"] += r["bytes"]; g["launches"] += r["launches"]
+            memory_bound = [{"kernel": g["kernel"], "launches_per_step": g["launches"] / nprof, "ms_per_step": g["ms"] / nprof,
+                             "algorithmic_GBps": g["bytes"] / (g["ms"] * 1e-3) / 1e9,
+                             "frac_of_hbm_peak": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                            for g in sorted(groups.values(), key=lambda g: -g["ms"]) if g["ms"] > 0]
+            whole = None
+            if pmc["kernels"] is not None and pmc.get("whole_step_bytes"):
+                whole = {"hbm_bytes_per_step": pmc["whole_step_bytes"], "algorithmic_bytes_per_step": args.batch * step_bytes,
+                         "ratio": pmc["whole_step_bytes"] / (args.batch * step_bytes)}
             roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": peak,
                         "peak_note": ("2500 TFLOP/s dense bf16 MFMA" if is_bf else "2500 TFLOP/s dense f16 MFMA / 3 passes per fp32-equivalent product" if is_split
                                       else "fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
                         "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                        "traffic_whole_step": whole,
                         "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
                         "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                         "mfma_kernels_ms_per_step": mfma_ms,
-                        "all_mfma_kernels_achieved": sum(r["flops"] for r in rows) / nprof / (mfma_ms * 1e-3) / 1e12,
+                        "all_mfma_kernels_achieved": sum(r["flops"] for r in gemm_rows) / nprof / (mfma_ms * 1e-3) / 1e12,
                         "top5": [{"kernel": r["kernel"], "ms_per_step": r["ms"] / nprof,
-                                  "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12} for r in rows[:(999 if os.environ.get("WUNET_BENCH_ALL") else 5)]]}
+                                  "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12} for r in gemm_rows[:(999 if os.environ.get("WUNET_BENCH_ALL") else 5)]],
+                        "memory_bound_kernels": memory_bound,
+                        "memory_bound_ms_per_step": sum(m["ms_per_step"] for m in memory_bound)}
+
+    # ---- extras the driver should see next to the headline (same box, same process): the exact-fp32 arithmetic and the
+    #      eval-mode forward (BASELINE configs[1])
+    extras = None
+    if rank == 0 and world == 1 and args.mode == "train" and default_net and not args.no_extras:
+        extras = {}
+        torch.manual_seed(0)
+        m32 = pkg.Model(n_layers=args.layers, channels_interval=CI).to(device).train()
+        m32._engine_override = engine_mod.Engine(h3=0)
+        c32 = pkg.smooth_l1_loss()
+        c32._engine_override = m32._engine_override
+        o32 = adam_cls(m32.parameters(), lr=1e-3, betas=(0.9, 0.999))
+
+        def step32():
+            o32.zero_grad(set_to_none=True)
+            c32(clean, m32(noisy)).backward()
+            o32.step()
+        extras["gemm_fp32"] = timed(step32, 3, 10, args.batch, "training step, every GEMM on v_mfma_f32_16x16x4_f32 (exact fp32: WUNET_H3=0)")
+        del m32, o32
+        model.eval()
+
+        def fwd():
+            with torch.no_grad():
+                model(noisy)
+        extras["eval_forward"] = timed(fwd, 5, 20, args.batch, "eval-mode forward only (BASELINE configs[1], enhancement.py path), default GEMM arithmetic")
+        model.train()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -314,7 +397,7 @@ def main():
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
             "step_launch": "one hipGraph replay per step" if use_graph else "eager (~270 kernel launches per step)",
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(result))
 

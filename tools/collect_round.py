@@ -1,0 +1,42 @@
+"""Copies the summaries of a tools/measure_round.sh run (gpurun_out/final) into profiles/ under a tag and rebuilds
+profiles/pmc_traffic.json.  Usage: python tools/collect_round.py r2"""
+import csv, json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+
+tag = sys.argv[1]
+F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
+for src, dst in (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_bf16.json"), ("bench_deep16_bf16.json", "bench_deep16_bf16.json"),
+                 ("bench_deep16_split.json", "bench_deep16_split.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
+                 ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
+                 ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
+                 ("fwd_kernel_stats.csv", "forward_kernel_stats.csv")):
+    if os.path.exists(os.path.join(F, src)):
+        shutil.copy(os.path.join(F, src), os.path.join(P, f"{tag}_{dst}"))
+raw = json.load(open(os.path.join(F, "pmc_raw.json")))
+# the PMC runs execute 3 steps (1 warm-up + 2): launches / 3 = launches per step.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE
+# under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section): doubled.
+kern, whole = {}, 0.0
+for k, (n, fs) in raw["fetch"].items():
+    wn, ws = raw["write"].get(k, [0, 0.0])
+    per = (2.0 * fs / n + (ws / wn if wn else 0.0)) * 1024.0
+    kern[k] = {"launches_per_step": n / 3.0, "FETCH_SIZE_KiB": round(fs / n, 1), "WRITE_SIZE_KiB": round(ws / wn if wn else 0.0, 1),
+               "hbm_bytes_per_launch": int(per)}
+    whole += per * n / 3.0
+out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1; HBM bytes per "
+                "launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction); whole_step_bytes = sum over ALL kernels of one step, "
+                "torch's own (optimizer state init, fills) included",
+       "tag": tag, "source_hash": bench.source_hash(), "whole_step_bytes": whole, "kernels": kern}
+json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
+shutil.copy(os.path.join(P, "pmc_traffic.json"), os.path.join(P, f"{tag}_pmc_traffic.json"))
+print("whole step HBM bytes %.3f GB" % (whole / 1e9))
+for name in ("bench.json", "bench_gemm_bf16.json", "bench_deep16_bf16.json", "bench_deep16_split.json", "serial_bench.json", "forward_bench.json"):
+    pth = os.path.join(P, f"{tag}_{name}")
+    if not os.path.exists(pth):
+        continue
+    j = json.loads(open(pth).read().strip().splitlines()[-1]); r = j.get("roofline") or {}
+    print(name, round(j["value"]), round(j["ms_per_step"], 3), r.get("kernel"), r.get("achieved") and round(r["achieved"], 1), r.get("frac") and round(r["frac"], 3), r.get("avg_launch_ms"))
+rows = list(csv.DictReader(open(os.path.join(P, f"{tag}_serial_bench_kernel_stats.csv"))))
+for r in rows[:5]:
+    print("serial", r["Name"][:60], r["Calls"], "avg %.4f ms" % (float(r["AverageNs"]) / 1e6))

@@ -858,10 +858,18 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                     size_t hb1 = (nt * 4 + WUNET_THREADS - 1) / WUNET_THREADS;            // one thread per sample and channel group
                     if (hb1 > 65536) hb1 = 65536;
                     const dim3 g1((unsigned)hb1), t1(WUNET_THREADS);
+                    // algorithmic bytes of the operand pass (HBM-bound): fp32 sources read once, 2 + 2 (bf16: 2) bytes per value written
+                    const double ob = c->bf ? 2.0 : 4.0, pe = (double)c->B * l.L;
+                    const int mode = ph.up_only ? 3 : ph.kind ? 2 : ph.sh ? 1 : 0;
+                    const double pbytes = mode == 0 ? pe * l.cin * (8.0 + ob) : mode == 1 ? pe * l.cin * (8.0 + 3.0 * ob)
+                                        : mode == 2 ? pe * (ph.C0 * 2.0 + ph.C1 * 4.0 + l.cin * ob) : pe * ph.C0 * (2.0 + ob);
+                    static const char* const pn[4] = {"prep_h3_kernel<0>", "prep_h3_kernel<1>", "prep_h3_kernel<2>", "prep_h3_kernel<3>"};
+                    prof_begin(st, pn[mode], 0.0, pbytes);
                     if (ph.up_only) WUNET_LAUNCH((prep_h3_kernel<3>), g1, t1, 0, st, ph);
                     else if (ph.kind) WUNET_LAUNCH((prep_h3_kernel<2>), g1, t1, 0, st, ph);
                     else if (ph.sh) WUNET_LAUNCH((prep_h3_kernel<1>), g1, t1, 0, st, ph);
                     else WUNET_LAUNCH((prep_h3_kernel<0>), g1, t1, 0, st, ph);
+                    prof_end(st);
                 }
             } else if (l.L < 4) {
                 if (l.kind == LK_UPCAT) {
@@ -905,9 +913,11 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_CHECK_LAUNCH();
         }
         if (l.first) {
+            prof_begin(st, "conv_first_kernel<15>", 2.0 * c->B * l.L * l.cout * 15.0, 4.0 * c->B * l.L * (1.0 + l.cout));
             WUNET_LAUNCH(conv_first_kernel<15>, dim3((unsigned)l.f.grid_x), dim3(WUNET_THREADS), 0, st, xin, params[4 * i], params[4 * i + 1],
                          ws + l.z, training ? ws + c->stats_off : (float*)nullptr, c->B, l.cout, l.L, l.logL,
                          ev_epi ? ws + l.a : (const float*)nullptr, ev_epi ? ws + l.s : (const float*)nullptr, ev_epi ? xrows : (float*)nullptr);
+            prof_end(st);
         } else if (l.h3f) {
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
             wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);
@@ -977,7 +987,9 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         h.B = c->B; h.C = c->ci; h.T = c->T; h.logT = ilog2(c->T);
         long long blocks = ((long long)c->B * c->T + WUNET_THREADS - 1) / WUNET_THREADS;
         if (blocks > 4096) blocks = 4096;
+        prof_begin(st, "head_fwd_kernel", 2.0 * c->B * c->T * (c->ci + 1.0), 4.0 * c->B * c->T * (c->ci + 2.0));
         WUNET_LAUNCH(head_fwd_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, h);
+        prof_end(st);
         WUNET_CHECK_LAUNCH();
     }
     return WUNET_OK;
@@ -1067,9 +1079,15 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
             p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.L;
         }
+        {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
+            const double pe = (double)c->B * l.cout * l.L;
+            const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : "pass_a_kernel<ENC>";
+            prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? 8.0 : i >= n ? 16.0 : 14.0) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
+        }
         if (i == NL - 1) {
             p.g0 = ws + c->gh_off; p.g1 = params[4 * NL]; p.hpart = ws + c->hpart2_off;
             WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);      // (the last layer has T >= 4 samples)
+            prof_end(st);
             WUNET_CHECK_LAUNCH();
             WUNET_LAUNCH(rows_sum_kernel, dim3(c->ci), dim3(WUNET_THREADS), 0, st,
                          (const float*)(ws + c->hpart2_off), l.a_split, c->ci, grads[4 * NL], c->ci, grads[4 * NL + 1]);
@@ -1081,6 +1099,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_UP, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
+            prof_end(st);
         } else {
             const LayerPlan& dc = c->ly[2 * n - i];
             const LayerPlan& nx = c->ly[i + 1];
@@ -1088,6 +1107,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_ENC, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
+            prof_end(st);
         }
         WUNET_CHECK_LAUNCH();
         if (!fuse) {
@@ -1109,10 +1129,12 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     const size_t nt = (size_t)c->B * c8 * (l.L / 4);
                     size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                     if (hb > 8192) hb = 8192;
+                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * (8.0 + (c->bf ? 2.0 : 4.0)));
                     WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                  (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
                                  ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
                                  c->B, l.cout, c8, l.L, l.logL, c->bf);
+                    prof_end(st);
                 } else if (tiny)
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
                                  (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
