@@ -14,7 +14,10 @@ FP = ctypes.POINTER(ctypes.c_float)
 def lib():
     global _LIB
     if _LIB is None:
-        subprocess.run(["make", "-C", os.path.join(_HERE, "emu"), "-s", "-j8"], check=True)
+        import fcntl
+        with open(os.path.join(_HERE, "emu", ".build.lock"), "w") as lk:      # pytest-xdist workers must not rebuild concurrently
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            subprocess.run(["make", "-C", os.path.join(_HERE, "emu"), "-s", "-j8"], check=True)
         L = ctypes.CDLL(os.path.join(_HERE, "emu", "libwunet_emu.so"))
         L.wunet_last_error.restype = ctypes.c_char_p
         L.wunet_workspace_bytes.restype = ctypes.c_size_t
