@@ -13,8 +13,8 @@ cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o conc -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python $R/bench.py --no-cpu-baseline --no-extras > $O/serial_bench.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd -o fwd -- python $R/bench.py --mode forward --no-cpu-baseline --no-roofline > $O/forward_bench.json 2>/dev/null
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+WUNET_BENCH_NO_MEDIAN=1 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+WUNET_BENCH_NO_MEDIAN=1 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
 # keep what collect_round.py needs, drop the bulky traces
 for d in conc serial fwd; do f=$(find $O/$d -name "${d}_kernel_stats.csv" | head -1); cp $f $O/${d}_kernel_stats.csv; g=$(find $O/$d -name "${d}_kernel_trace.csv" | head -1); [ "$d" = serial ] && cp $g $O/serial_kernel_trace.csv; rm -rf $O/$d; done
 python - <<PY
