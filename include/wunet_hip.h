@@ -125,6 +125,11 @@ int wunet_num_conv_layers(const wunet_ctx* ctx);
 int wunet_profile_enable(int on);
 long long wunet_profile_collect(char* buf, size_t cap);
 
+/* Measurement aid (tools/conv_trace.py; no reference counterpart): a device buffer of gridDim.x * 64 uint64 that the DMA-staged
+ * conv / data-gradient kernel (conv_h3d_kernel) fills with shader-clock stamps of each block's phases (entry; per K stage: tile
+ * landed, W buffer released, MFMAs issued; epilogue done), or NULL (default) to turn the stamps off.  Process-wide. */
+void wunet_debug_set_conv_trace(void* dev_buffer);
+
 /* Single-op entry points (parity tests of the MFMA kernels against F.conv1d semantics,
  * nn.Conv1d stride 1, padding K/2, K in {5, 15}).  They allocate scratch and synchronise. */
 int wunet_op_conv1d(const float* x, const float* w, const float* bias, float* z,

@@ -208,6 +208,16 @@ inline void wunet_dma16(const void* g, void* lds_wave_base)
     std::memcpy(static_cast<char*>(lds_wave_base) + 16 * lane, g, 16);
 }
 
+typedef char* wunet_lds_t;
+inline wunet_lds_t wunet_lds_addr(const void* p) { return (char*)p; }
+inline int wunet_uniform(int v) { return v; }
+inline void wunet_dma16a(const void* g, wunet_lds_t lds_wave_base) { wunet_dma16(g, lds_wave_base); }
+inline void wunet_wait_dma_barrier() { emu::block_barrier(); }
+inline void wunet_wait_lds_barrier() { emu::block_barrier(); }
+inline unsigned long long wunet_memtime() { return 0; }
+inline void wunet_opaque(int&) {}
+#define wunet_sched_fence() ((void)0)
+
 inline float wunet_shfl_xor(float v, int mask)
 {
     emu::FiberState& f = emu::cur_fiber();

@@ -134,17 +134,28 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
                                            ("WUNET_NO_SKIP_FUSE", 2, (4, 16, 3, 1024)),   # decoder-side pass reads the skip itself
                                            ("WUNET_NO_PASSA_FAST", 2, (4, 20, 3, 1024)),  # generic upsample-transpose walk
                                            ("WUNET_NO_PASSA_FUSE", 0, (4, 12, 5, 128)),   # separate BN-backward finalize + g_z
-                                           ("WUNET_H3_PAIR", 2, (2, 24, 2, 1024))])       # conv_h3p_kernel: two tiles per block, shared double-buffered W
+                                           ("WUNET_H3_PAIR", 2, (2, 24, 2, 1024)),        # conv_h3p_kernel: two tiles per block, shared double-buffered W
+                                           # conv_h3_kernel (register-staged x tile) instead of conv_h3d_kernel (DMA-staged, persistent):
+                                           # 8 blocks walk all work items, split-K stages
+                                           ("WUNET_H3_XDMA=0 WUNET_H3_GRID=8", 2, (2, 24, 2, 1024)),
+                                           # ... un-split (bias + BatchNorm statistics in the epilogue), 64-row blocks, edge tiles of every item
+                                           ("WUNET_H3_XDMA=0 WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1 WUNET_H3_ORDER=432 WUNET_H3D_ORDER=432", 2, (2, 32, 3, 1024)),
+                                           # ... channel counts off the 8 / 32 grid (zero-page pieces in the last chunk), 16 blocks
+                                           ("WUNET_H3_XDMA=0 WUNET_H3_GRID=16 WUNET_H3_NOSPLIT=1", 2, (1, 20, 3, 2048))])
 def test_measurement_switches_are_bit_identical(switch, h3, cfg, monkeypatch):
-    """The fused / re-mapped elementwise kernels of the default path compute exactly what the forms they replaced compute:
-    one training step with and without the A/B switch gives the same output and the same gradients, bit for bit."""
+    """The fused / re-mapped kernels of the default path compute exactly what the forms they replaced compute:
+    one training step with and without the A/B switch gives the same output and the same gradients, bit for bit.
+    ("A=v B=w ...": A=v is the switch, the other settings hold for both runs.)"""
     n, ci, B, T = cfg
     eng_mod = importlib.import_module(PKG_NAME + ".engine")
     lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    settings = [kv.split("=") if "=" in kv else [kv, "1"] for kv in switch.split()]
+    for k, v in settings[1:]:
+        monkeypatch.setenv(k, v)
     results = []
     for on in (False, True):
         if on:
-            monkeypatch.setenv(switch, "1")
+            monkeypatch.setenv(settings[0][0], settings[0][1])
         eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=h3)
         m, sd, pkg_loss = _build(n, ci, eng)
         noisy, clean = plan.golden_batch(B, T, 0)

@@ -463,7 +463,9 @@ def test_split_ops_at_baseline_geometries(engine, dev, prefix, Cin, Cout, K, L):
         assert lib.wunet_op_conv1d_wgrad_split(gd.data_ptr(), xd.data_ptr(), dw.data_ptr(), B, Cin, Cout, L, K, None) == 0, lib.wunet_last_error()
     names = _profiled_kernels(lib, run)
     torch.cuda.synchronize()
-    assert sum(nm.startswith(("conv_h3_kernel<%d," % K, "conv_h3p_kernel<%d," % K)) for nm in names) >= 1, names
+    assert sum(nm.startswith(("conv_h3_kernel<%d," % K, "conv_h3d_kernel<%d," % K, "conv_h3p_kernel<%d," % K)) for nm in names) >= 1, names
+    if L >= 256:      # the un-segmented levels run the DMA-staged, pipelined kernel
+        assert any(nm.startswith("conv_h3d_kernel<%d," % K) for nm in names), names
     wg = [nm for nm in names if nm.startswith("wgrad_h3")]
     assert len(wg) == 1 and wg[0].startswith(("wgrad_h3d_kernel<%d," if L >= 128 else "wgrad_h3_kernel<%d,") % K), names
 

@@ -1,0 +1,22 @@
+// Instantiation unit: conv_h3d_kernel<TAPS, M_REP, NSEG, BF> (fp16-split conv / data gradient, DMA-staged and pipelined).
+#include "wunet_h3d.h"
+#include "wunet_launch.h"
+
+#define WUNET_XCASE(T, M, S)                                                                               \
+    if (taps == T && mrep == M && nseg == S) {                                                             \
+        if (bf) {                                                                                          \
+            if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<T, M, S, true>), smem) != 0) return -2;               \
+            WUNET_LAUNCH((conv_h3d_kernel<T, M, S, true>), grid, dim3(WUNET_THREADS), smem, st, a);        \
+        } else {                                                                                           \
+            if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<T, M, S>), smem) != 0) return -2;                     \
+            WUNET_LAUNCH((conv_h3d_kernel<T, M, S>), grid, dim3(WUNET_THREADS), smem, st, a);              \
+        }                                                                                                  \
+        return 0;                                                                                          \
+    }
+
+int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf)
+{
+    WUNET_XCASE(15, 2, 1) WUNET_XCASE(15, 3, 1) WUNET_XCASE(15, 4, 1)
+    WUNET_XCASE(5, 2, 1) WUNET_XCASE(5, 3, 1) WUNET_XCASE(5, 4, 1)
+    return -1;
+}

@@ -349,7 +349,7 @@ size_t h3w_part_stride(const LayerPlan& l)
 // exist; returns the stages per split (== nstage: no split).
 int h3_stages_per_split(int blocks, int nstage)
 {
-    if (blocks >= 384 || nstage <= 1) return nstage;
+    if (blocks >= 384 || nstage <= 1 || getenv("WUNET_H3_NOSPLIT")) return nstage;      // (switch: tests reach the un-split epilogue on small shapes)
     int ks = (512 + blocks - 1) / blocks;
     if (ks > nstage) ks = nstage;
     return (nstage + ks - 1) / ks;
@@ -569,6 +569,35 @@ bool h3_conv_is_paired(int B, int L)
     return pair_env && L >= 256 && (posn & 511) == 0;
 }
 
+// conv_h3d_kernel (DMA-staged, pipelined, persistent) runs instead of conv_h3_kernel: un-segmented tiles (L >= 256)
+bool h3_conv_is_dma(int L)
+{
+    const char* e = getenv("WUNET_H3_XDMA");            // A/B switch (read per launch: tests toggle it)
+    return L >= 256 && !(e && atoi(e) == 0);
+}
+
+// resident conv_h3d blocks the grid is sized for: two per CU (its launch bounds); WUNET_H3_GRID overrides (tests: a few blocks walk
+// many work items)
+int h3_grid_cap()
+{
+    if (const char* e = getenv("WUNET_H3_GRID")) { const int v = atoi(e); if (v > 0) return v; }
+#ifdef WUNET_EMU
+    return 1 << 30;
+#else
+    static int cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return 2 * cus[dev];
+#endif
+}
+
+unsigned long long* g_h3_trace = nullptr;       // wunet_debug_set_conv_trace
+
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr,
@@ -585,10 +614,24 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     a.stages_per_split = sps; a.split_stride = (size_t)B * rows * L;
 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
+    a.trace = g_h3_trace;
     // paired tiles (conv_h3p_kernel: two tiles per 512-thread block, double-buffered shared W) for L >= 256 with an even tile count
     const bool paired = !bf && h3_conv_is_paired(B, L);     // (A/B switch: WUNET_H3_PAIR=1)
     int rc;
-    if (paired) {
+    if (!paired && h3_conv_is_dma(L)) {
+        // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
+        snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
+        prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)));
+        const int npl = bf ? 1 : 2;
+        const size_t smem = (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4) * sizeof(float);
+        const int nitems = a.ntiles * a.mblocks;
+        int gx = h3_grid_cap() / ksplit;
+        gx &= ~7;
+        if (gx < 8) gx = 8;
+        if (gx > nitems) gx = nitems;
+        const dim3 grid((unsigned)gx, (unsigned)ksplit);
+        rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0);
+    } else if (paired) {
         snprintf(pname, sizeof pname, "conv_h3p_kernel<%d, %d>", taps, mrep);
         prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
         const size_t smem = (size_t)(2 * 2 * 4 * 272 + 2 * 2 * mrep * 5 * 64) * 16;
@@ -671,6 +714,8 @@ wunet_ctx::Side* side_for_current_device(wunet_ctx* c)
 extern "C" {
 
 const char* wunet_last_error(void) { return g_err.c_str(); }
+
+void wunet_debug_set_conv_trace(void* dev_buffer) { g_h3_trace = static_cast<unsigned long long*>(dev_buffer); }
 
 int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out)
 {

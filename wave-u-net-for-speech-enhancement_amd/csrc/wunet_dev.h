@@ -99,6 +99,33 @@ __device__ __forceinline__ void wunet_dma16(const void* g, void* lds_wave_base)
 __device__ __forceinline__ void wunet_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // wave issue priority 0..3 (s_setprio)
 #define wunet_setprio(N_) __builtin_amdgcn_s_setprio(N_)
+// The same DMA issued from inline asm (conv_h3d_kernel): hipcc does not see a VMEM / LDS-DMA instruction, so it neither puts its
+// conservative "s_waitcnt vmcnt(0)" in front of every later LDS read (it cannot tell the buffers apart) nor counts the piece in
+// its own vmcnt arithmetic (extra pieces in flight only make its counted waits wait longer, loads return in order).  The kernel
+// places every wait itself: wunet_wait_dma_barrier() before the first read of a DMA-written buffer, wunet_wait_lds_barrier()
+// before a buffer is handed back to the DMA engine.  M0 (the LDS base of the instruction) is saved and restored.
+typedef unsigned wunet_lds_t;      // LDS byte address
+__device__ __forceinline__ wunet_lds_t wunet_lds_addr(const void* p)
+{
+    return (unsigned)(__UINTPTR_TYPE__)(__attribute__((address_space(3))) const char*)p;
+}
+__device__ __forceinline__ int wunet_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }   // v is the same in every lane of the wave
+__device__ __forceinline__ void wunet_dma16a(const void* g, wunet_lds_t lds_wave_base)
+{
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+// every DMA piece this wave issued has landed, then the workgroup barrier: all pieces of all waves are visible in LDS
+__device__ __forceinline__ void wunet_wait_dma_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
+// every LDS read / write this wave issued has completed, then the barrier (no vmcnt wait: DMAs stay in flight across it)
+__device__ __forceinline__ void wunet_wait_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned long long wunet_memtime() { return __builtin_amdgcn_s_memtime(); }
+// nothing is scheduled across this point (hipcc otherwise sinks LDS prefetches to their first use)
+#define wunet_sched_fence() __builtin_amdgcn_sched_barrier(0)
+// the value becomes opaque to the optimiser (no hoisting of what is derived from it)
+__device__ __forceinline__ void wunet_opaque(int& v) { asm volatile("" : "+v"(v)); }
 #endif
 
 // hi/lo fp16 split of s*x (s a power of two chosen so that |s*x| stays far below 65504)

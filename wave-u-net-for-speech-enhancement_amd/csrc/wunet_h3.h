@@ -32,6 +32,7 @@ struct ConvH3Args {
     // eval mode (BatchNorm coefficients known before the conv): ev_a / ev_s = scale / shift of this layer's BatchNorm, xrows
     // [gridDim.x] receives the block's max |a (v + bias) + s| - the activation bound the consumers' operand scale derives from
     const float* ev_a; const float* ev_s; float* xrows;
+    unsigned long long* trace;                    // nullptr, or [gridDim.x][64] shader-clock stamps of the block's phases (conv_h3d_kernel; tools/conv_trace.py)
     int B, Cout, C8, NCH, L, logL;
     int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)

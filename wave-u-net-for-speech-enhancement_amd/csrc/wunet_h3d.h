@@ -1,0 +1,312 @@
+// conv_h3d_kernel: the GEMM of conv_h3_kernel (same LDS images, same fragments, same order of the MFMAs of every accumulator:
+// bit-identical results) with the staging rebuilt around the LDS-DMA engine so that a block fetches while it computes:
+//   * the x tile is staged by global_load_lds_dwordx4 as well - the de-interleave of the columns is done by the per-lane SOURCE
+//     address (lane i's 16 bytes always land at wave base + 16 i); halo pieces outside the item and channel groups beyond C8 fetch
+//     a 16-byte zero page.  No staging registers, no ds_write pass, no selects.
+//   * every LDS buffer is handed back to the DMA engine as soon as its last fragment has been read, not at the end of the
+//     stage: the 8 B-fragment pairs of a stage are read up front, so the x tile is free right after them and the NEXT x tile
+//     (next chunk, or the first chunk of the block's next work item) lands under this stage's MFMAs; the A fragments are read one
+//     tap ahead, so the W sub-tile is free before the last tap and the next one lands under the rest of the MFMAs.
+//     The waits are hand-placed (s_waitcnt lgkmcnt(0) + s_barrier to release a buffer, vmcnt(0) + s_barrier at the top of a stage);
+//     the DMA instructions are issued from inline asm so that hipcc's conservative "vmcnt(0) before any LDS read that follows an
+//     LDS-DMA" cannot serialise the pipeline again.
+//   * blocks are persistent: a block walks work items (position tile, row block) blockIdx.x, blockIdx.x + gridDim.x, ...; the first
+//     stage of the next item is fetched under the last stage and the epilogue of the current one.
+// The MFMAs of a tap are issued pass-major (all accumulators' lo*hi, then hi*lo, then hi*hi): 4*M_REP independent MFMAs between two
+// MFMAs on the same accumulator instead of hipcc's back-to-back chains.
+#pragma once
+#include "wunet_h3.h"
+
+#ifdef WUNET_EMU
+static const unsigned wunet_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+static __device__ __attribute__((aligned(16))) const unsigned wunet_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+template <int TAPS, int M_REP, int NSEG, bool BF = false>
+__global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A)
+{
+    constexpr int PAD = TAPS / 2;
+    constexpr int TG = 5;                         // taps per stage
+    constexpr int NTG = TAPS / TG;
+    constexpr int LSEG = 256 / NSEG, SW = LSEG + 16;
+    constexpr int COLS = NSEG * SW, Q4 = COLS / 4;
+    constexpr int NPL = BF ? 1 : 2;
+    constexpr int XP = NPL * 4 * COLS;            // 16-byte pieces of the x tile
+    constexpr int WPM = TG * 64;
+    constexpr int WP = NPL * M_REP * WPM;         // pieces of the W sub-tile of a stage
+    constexpr int WIT = (WP + WUNET_THREADS - 1) / WUNET_THREADS;
+    static_assert(XP % 64 == 0 && WP % 64 == 0, "whole DMA instructions per wave");
+    WUNET_DYN_SMEM(smem);
+    wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS, de-interleaved][8]
+    wunet_half* ws = xs + XP * 8;                                      // [hi|lo][M_REP][TG][4][16][8]
+    float* red = reinterpret_cast<float*>(ws + WP * 8);                // [4 waves][M_REP * 16][2] statistics hand-over, + 4 maxima
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
+    const int L = A.L;
+    const wunet_half* const zero = reinterpret_cast<const wunet_half*>(wunet_zero16);
+
+    // ---- per-thread source descriptors of its DMA pieces (independent of the work item).  A DMA instruction of a wave writes one
+    // RUN of 64 consecutive pieces; the runs of the x image ([plane][4 groups][COLS, de-interleaved]: RP runs per plane) are dealt
+    // so that the plane of an instruction is a compile-time constant: instruction it < NPL*XF covers runs 4 (it % XF) + wave of
+    // plane it / XF, the XR left-over runs of every plane share one last instruction (wave -> plane wave / XR, run 4 XF + wave % XR).
+    // Piece p of a plane is (channel group c8 = p / COLS, column col = 4 (w % Q4) + w / Q4 with w = p % COLS - the de-interleave);
+    // xmeta = c8 | item of the tile << 4 | (sample - l0 + 8) << 12 | plane << 28, or -1 for an idle wave of the last instruction.
+    constexpr int RP = 4 * COLS / 64, XF = RP / 4, XR = RP % 4;
+    constexpr int XIT = NPL * XF + (XR ? 1 : 0);
+    static_assert(XR * NPL <= 4, "left-over runs fit one instruction");
+    int xmeta[XIT];
+    int xrun = 0;                                   // run (within its plane) of this wave in the last, shared instruction
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        int pl = it / XF, run = 4 * (it % XF) + wave;
+        bool live = true;
+        if (it == NPL * XF) { pl = wave / (XR ? XR : 1); run = 4 * XF + wave % (XR ? XR : 1); live = wave < XR * NPL; xrun = run; }
+        const int p = run * 64 + lane, c8 = p / COLS, w = p % COLS;
+        const int col = 4 * (w % Q4) + w / Q4, seg = col / SW, lrel = col - seg * SW - 8;
+        xmeta[it] = live ? (c8 | (seg << 4) | ((lrel + 8) << 12) | (pl << 28)) : -1;
+    }
+    // W sub-tile [hi|lo][M_REP][TG][64 pieces]: piece f = tid + 256 it; woff = halfs from the stage's first piece in the pack | lo << 30
+    int woff[WIT];
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+        const int f = tid + it * WUNET_THREADS;
+        const int which = f / (M_REP * WPM), r = f % (M_REP * WPM), mt = r / WPM, p = r % WPM;
+        woff[it] = ((mt * A.NCH * TAPS * 64 + p) * 8) | (which << 30);
+    }
+    const wunet_lds_t xs_a = wunet_lds_addr(xs), ws_a = wunet_lds_addr(ws);
+    const int wave_u = wunet_uniform(wave);
+    const long long zero_a = (long long)reinterpret_cast<size_t>(zero);
+    // (the descriptors are made opaque at every use: hipcc would otherwise hoist one 64-bit address per piece out of the stage
+    // loop and carry 34 more registers through the MFMA phase; the selects are arithmetic so that the issue stays ONE basic block)
+#define WUNET_H3D_X_PIECE(IT_, B_, L0_, CH_, XH_, XL_)                                                            \
+    {                                                                                                             \
+        int m_ = xmeta[IT_];                                                                                      \
+        wunet_opaque(m_);                                                                                         \
+        const int c8_ = m_ & 15, seg_ = (m_ >> 4) & 255, lrel_ = ((m_ >> 12) & 0xffff) - 8;                       \
+        const bool ok_ = (CH_) * 4 + c8_ < A.C8 && (unsigned)((L0_) + lrel_) < (unsigned)L && (B_) + seg_ < A.B;  \
+        const int off_ = ((seg_ * A.C8 + c8_) * L + lrel_) * 16;                                                  \
+        const long long real_ = ((IT_) < NPL * XF ? ((IT_) / XF ? (XL_) : (XH_)) : (((m_ >> 28) & 1) ? (XL_) : (XH_))) + off_; \
+        const long long a_ = zero_a + ((real_ - zero_a) & -(long long)ok_);                                       \
+        const int run_ = (IT_) < NPL * XF ? 4 * ((IT_) % XF) + wave_u : wunet_uniform(xrun);                      \
+        const int pl_ = (IT_) < NPL * XF ? (IT_) / XF : wunet_uniform((m_ >> 28) & 1);                            \
+        wunet_dma16a(reinterpret_cast<const void*>(a_), xs_a + (pl_ * 4 * COLS + run_ * 64) * 16);                \
+    }
+#define WUNET_H3D_ISSUE_X(B_, L0_, CH_)                                                                           \
+    {                                                                                                             \
+        const long long boff_ = (long long)((((size_t)(B_) * A.C8 + (CH_) * 4) * L + (L0_)) * 16);                \
+        const long long xh_ = (long long)reinterpret_cast<size_t>(A.xh) + boff_, xl_ = (long long)reinterpret_cast<size_t>(A.xl) + boff_; \
+        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
+            if (it < NPL * XF) WUNET_H3D_X_PIECE(it, B_, L0_, CH_, xh_, xl_)                                      \
+            else if (xmeta[it] >= 0) WUNET_H3D_X_PIECE(it, B_, L0_, CH_, xh_, xl_)                                \
+        }                                                                                                         \
+    }
+#define WUNET_H3D_ISSUE_W(MT0_, CH_, TG_)                                                                         \
+    {                                                                                                             \
+        const long long boff_ = (long long)(((((size_t)(MT0_) * A.NCH + (CH_)) * TAPS + (TG_) * TG) * 64) * 16);  \
+        const long long wh_ = (long long)reinterpret_cast<size_t>(A.wh) + boff_, wl_ = (long long)reinterpret_cast<size_t>(A.wl) + boff_; \
+        _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
+            if ((it + 1) * WUNET_THREADS <= WP || tid + it * WUNET_THREADS < WP) {                                \
+                int m_ = woff[it];                                                                                \
+                wunet_opaque(m_);                                                                                 \
+                const long long sel_ = -(long long)((m_ >> 30) & 1);                                              \
+                const long long a_ = wh_ + ((wl_ - wh_) & sel_) + (long long)(m_ & 0x3fffffff) * 2;               \
+                wunet_dma16a(reinterpret_cast<const void*>(a_), ws_a + (it * WUNET_THREADS + wave_u * 64) * 16);  \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+    // work item v -> (position tile, row block): the row blocks of one tile on ONE XCD (they share its x tile in that L2);
+    // gridDim.x is a multiple of 8 whenever a block walks more than one item, so the XCD of an item is the block's
+#define WUNET_H3D_ITEM(V_, TILE_, MBLK_)                                                                          \
+    if ((A.ntiles & 7) == 0) {                                                                                    \
+        const int xcd_ = (V_) & 7, k_ = (V_) >> 3;                                                                \
+        MBLK_ = k_ % A.mblocks;                                                                                   \
+        TILE_ = (k_ / A.mblocks) * 8 + xcd_;                                                                      \
+    } else {                                                                                                      \
+        MBLK_ = (V_) % A.mblocks;                                                                                 \
+        TILE_ = (V_) / A.mblocks;                                                                                 \
+    }
+#define WUNET_H3D_STAMP(K_)                                                                                       \
+    if (A.trace) {                                                                                                \
+        const unsigned long long t_ = wunet_memtime();                                                            \
+        if (tid == 0 && (K_) < 64) A.trace[(size_t)blockIdx.x * 64 + (K_)] = t_;                                  \
+    }
+
+    const int G = gridDim.x, nitems = A.ntiles * A.mblocks;
+    int v = blockIdx.x;
+    if (v >= nitems) return;
+    int tile, mblk;
+    WUNET_H3D_ITEM(v, tile, mblk)
+    int b = (tile * 256) >> A.logL, l0 = NSEG == 1 ? ((tile * 256) & (L - 1)) : 0, mt0 = mblk * M_REP;
+    const bool split = gridDim.y > 1;
+    const int st_beg = blockIdx.y * A.stages_per_split;
+    const int nstage = (st_beg + A.stages_per_split < A.NCH * NTG) ? st_beg + A.stages_per_split : A.NCH * NTG;
+    int stamp = 0;
+    WUNET_H3D_STAMP(stamp) ++stamp;
+    if (st_beg < nstage) {
+        WUNET_H3D_ISSUE_X(b, l0, st_beg / NTG)
+        WUNET_H3D_ISSUE_W(mt0, st_beg / NTG, st_beg % NTG)
+    }
+
+    // this lane's 4 positions wave*64 + 4*i16 .. +3 lie in ONE batch item of the tile: item lseg, first sample ll0
+    const int lpos = wave * 64 + i16 * 4;
+    const int lseg = lpos / LSEG, ll0 = lpos - lseg * LSEG;
+    const int boff = (q * COLS + ((lseg * SW + ll0) >> 2)) * 8;
+    const int aoff = (q * 16 + i16) * 8;
+
+    for (;;) {
+        const bool more = v + G < nitems;
+        int ntile = 0, nmblk = 0;
+        if (more) { WUNET_H3D_ITEM(v + G, ntile, nmblk) }
+        const int nb = (ntile * 256) >> A.logL, nl0 = NSEG == 1 ? ((ntile * 256) & (L - 1)) : 0, nmt0 = nmblk * M_REP;
+
+        wunet_f4 acc[M_REP][4];
+#pragma unroll
+        for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
+
+        for (int st = st_beg; st < nstage; ++st) {
+            const int ch = st / NTG, tg = st - ch * NTG;
+            const bool last = st + 1 == nstage, has_next = !last || more;
+            const int nst = last ? st_beg : st + 1, nch = nst / NTG, ntg = nst - nch * NTG;
+            const bool x_next = has_next && (last || nch != ch);
+            wunet_setprio(0);
+            wunet_wait_dma_barrier();             // this stage's x tile and W sub-tile have landed (every wave waited for its own pieces)
+            WUNET_H3D_STAMP(stamp) ++stamp;
+            wunet_setprio(3);
+            // B fragments slide: with the interleaved column mapping fragment (n-tile nt, tap) is column 4*lane + nt + tap = F[nt + tap]
+            wunet_h8 fh[TG + 3], fl[TG + 3];
+#pragma unroll
+            for (int e = 0; e < TG + 3; ++e) {
+                const int ec = tg * TG + e + 8 - PAD;
+                const int po = ((ec & 3) * Q4 + (ec >> 2)) * 8;
+                fh[e] = wunet_ldh8(xs + boff + po);
+                if (!BF) fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
+            }
+            wunet_h8 ah[2][M_REP], al[2][M_REP];
+#define WUNET_H3D_LOAD_A(BUF_, TL_)                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        ah[BUF_][mt] = wunet_ldh8(ws + ((mt * TG + (TL_)) * 64) * 8 + aoff);                                      \
+        if (!BF) al[BUF_][mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + (TL_)) * 64 * 8 + aoff);                     \
+    }
+#define WUNET_H3D_PASS(WHICH_, BUF_, TL_)                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
+            if (BF) { if ((WHICH_) == 2) acc[mt][nt] = wunet_mfma16b(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]); } \
+            else if ((WHICH_) == 0) acc[mt][nt] = wunet_mfma16h(al[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);       \
+            else if ((WHICH_) == 1) acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fl[(TL_) + nt], acc[mt][nt]);       \
+            else acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);                          \
+        }
+            WUNET_H3D_LOAD_A(0, 0)
+            if (x_next) {
+                wunet_wait_lds_barrier();         // every wave holds its B fragments: the x tile is free
+                if (last) { WUNET_H3D_ISSUE_X(nb, nl0, nch) } else { WUNET_H3D_ISSUE_X(b, l0, nch) }
+            }
+#pragma unroll
+            for (int tl = 0; tl < TG; ++tl) {
+                if (tl + 1 < TG) {
+                    if (tl & 1) { WUNET_H3D_LOAD_A(0, tl + 1) } else { WUNET_H3D_LOAD_A(1, tl + 1) }
+                }
+                wunet_sched_fence();              // the prefetch of the next tap's A fragments is ISSUED here, not sunk to its first use
+                if (tl & 1) { WUNET_H3D_PASS(0, 1, tl) } else { WUNET_H3D_PASS(0, 0, tl) }
+                if (tl == TG - 2) {
+                    // the last A fragments of this stage are in flight: once every wave has them the W sub-tile is free
+                    WUNET_H3D_STAMP(stamp)
+                    wunet_wait_lds_barrier();
+                    if (has_next) {
+                        if (last) { WUNET_H3D_ISSUE_W(nmt0, nch, ntg) } else { WUNET_H3D_ISSUE_W(mt0, nch, ntg) }
+                    }
+                }
+                if (tl & 1) { WUNET_H3D_PASS(1, 1, tl) WUNET_H3D_PASS(2, 1, tl) } else { WUNET_H3D_PASS(1, 0, tl) WUNET_H3D_PASS(2, 0, tl) }
+            }
+            ++stamp;
+            WUNET_H3D_STAMP(stamp) ++stamp;
+        }
+#undef WUNET_H3D_LOAD_A
+#undef WUNET_H3D_PASS
+
+        // ---- epilogue (conv_h3_kernel's): un-scale, bias, store, BN statistics of the bias-free conv; a K split stores its
+        // bias-free partial sum (statistics then come from the reduce kernel).  The DMAs of the next item's first stage are in flight.
+        wunet_setprio(0);
+        const float inv = A.sc ? A.sc[1] : 1.0f, inv2 = A.sc2 ? A.sc2[1] : 1.0f;
+        float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
+        const int bo = b + lseg;
+        float amax = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < M_REP; ++mt) {
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            const int l = l0 + ll0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (mt0 + mt) * 16 + q * 4 + r;
+                const float bv = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+                wunet_f4 o;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    const float vv = acc[mt][nt][r] * inv * inv2;
+                    s1[r] += vv;
+                    s2[r] += vv * vv;
+                    o[nt] = vv + bv;
+                }
+                if (co < A.Cout && bo < A.B) {
+                    wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
+                    if (A.xrows) {
+                        const float ea = A.ev_a[co], es = A.ev_s[co];
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
+                    }
+                }
+            }
+            if (A.stats && !split) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int m = 1; m < 16; m <<= 1) {
+                        s1[r] += wunet_shfl_xor(s1[r], m);
+                        s2[r] += wunet_shfl_xor(s2[r], m);
+                    }
+                    if (i16 == 0) {                               // per-wave sums of row mt*16 + q*4 + r -> LDS
+                        float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
+                        rp[0] = s1[r];
+                        rp[1] = s2[r];
+                    }
+                }
+            }
+        }
+        if (A.xrows) {                            // eval: block maximum of the activation bound (max is order independent)
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
+            float* rp = red + WUNET_WAVES * M_REP * 32;
+            if (lane == 0) rp[wave] = amax;
+            wunet_wait_lds_barrier();
+            if (tid == 0) A.xrows[v] = fmaxf(fmaxf(rp[0], rp[1]), fmaxf(rp[2], rp[3]));
+        }
+        // one statistics row per tile (256 positions): the four waves' sums are added in wave order
+        if (A.stats && !split) {
+            wunet_wait_lds_barrier();
+            if (tid < M_REP * 16) {
+                const float* rp = red + tid * 2;
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WUNET_WAVES; ++w) {
+                    t1 += rp[w * M_REP * 32];
+                    t2 += rp[w * M_REP * 32 + 1];
+                }
+                const int co = mt0 * 16 + tid;
+                if (co < A.Cout) {
+                    float* stp = A.stats + ((size_t)co * A.ntiles + tile) * 2;
+                    stp[0] = t1;
+                    stp[1] = t2;
+                }
+            }
+        }
+        WUNET_H3D_STAMP(stamp) ++stamp;
+        if (!more) break;
+        v += G; tile = ntile; b = nb; l0 = nl0; mt0 = nmt0;
+    }
+#undef WUNET_H3D_ISSUE_X
+#undef WUNET_H3D_ISSUE_W
+#undef WUNET_H3D_ITEM
+#undef WUNET_H3D_STAMP
+}
