@@ -229,6 +229,12 @@ inline float wunet_shfl_xor(float v, int mask)
     return blk.wave_a[wave][par][lane ^ mask];
 }
 
+inline float wunet_row16_sum(float v)
+{
+    for (int m = 1; m < 16; m <<= 1) v += wunet_shfl_xor(v, m);
+    return v;
+}
+
 // ---- minimal host runtime
 typedef void* hipStream_t;
 typedef int hipError_t;

@@ -105,7 +105,7 @@ def main():
     print("%-22s | " % "total fwd+dgrad" + " | ".join("%7.1f us %4.0f TF %17s" % (t[0], t[1] / max(t[0], 1e-9) / 1e6, "") for t in tot))
 
     if a.trace:
-        nblk = 2048
+        nblk = 8192
         tr = torch.zeros(nblk * 64, dtype=torch.int64, device=dev)
         for name, cin, cout, K, L in layers():
             if L < a.min_l or (want and name not in want):
@@ -117,8 +117,10 @@ def main():
             for cfg in a.cfgs:
                 if "XDMA=0" in cfg:
                     continue
+                saved = {}
                 for kv in cfg.split():
                     k, v = kv.split("=")
+                    saved[k] = os.environ.get(k)
                     os.environ[k] = v
                 lib.wunet_op_conv1d_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), B, cin, cout, L, K, None)
                 tr.zero_()
@@ -126,6 +128,11 @@ def main():
                 lib.wunet_op_conv1d_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), B, cin, cout, L, K, None)
                 lib.wunet_debug_set_conv_trace(None)
                 torch.cuda.synchronize()
+                for k, v in saved.items():
+                    if v is None:
+                        del os.environ[k]
+                    else:
+                        os.environ[k] = v
                 t = tr.cpu().numpy().reshape(nblk, 64)
                 t = t[t[:, 0] > 0]
                 if not len(t):
@@ -135,9 +142,8 @@ def main():
                 ns = int(np.median(nst))
                 t = t[nst == ns][:, :ns].astype(np.float64)
                 d = np.diff(t, axis=1)
-                print(f"trace {name} [{cfg}] blocks {len(t)} stamps/block {ns}: kernel span {((t.max() - t0) / 100.0):.1f} us (100 MHz clock?); "
-                      f"median deltas between stamps (ticks): " + " ".join("%d" % v for v in np.median(d, axis=0)))
-                print("      first-stamp spread (ticks): min %d median %d max %d" % (0, np.median(t[:, 0] - t0), (t[:, 0] - t0).max()))
+                print(f"trace {name} [{cfg}] blocks {len(t)} stamps/block {ns}: block span median {np.median(t[:, -1] - t[:, 0]):.0f} ticks; "
+                      f"median deltas between stamps (ticks): " + " ".join("%d" % v for v in np.median(d, axis=0)), flush=True)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,20 @@ __device__ __forceinline__ wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float wunet_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+// sum of v over the 16 lanes of a row (lanes 16k .. 16k+15), in every lane, by DPP moves (no LDS crossbar, no lgkmcnt wait):
+// lane ^ 1, lane ^ 2 inside a quad, then the mirrored lane of the 8-group and of the row - after the quad steps all lanes of a
+// quad hold one value and after the third all lanes of an 8-group, so the mirrored partner holds exactly what lane ^ 4 / lane ^ 8
+// holds: bit-identical to the shuffle butterfly  v += shfl_xor(v, 1), 2, 4, 8.
+__device__ __forceinline__ float wunet_row16_sum(float v)
+{
+#define WUNET_DPP_ADD(CTRL_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL_, 0xf, 0xf, false))
+    WUNET_DPP_ADD(0xB1);      // quad_perm [1,0,3,2]
+    WUNET_DPP_ADD(0x4E);      // quad_perm [2,3,0,1]
+    WUNET_DPP_ADD(0x141);     // row_half_mirror
+    WUNET_DPP_ADD(0x140);     // row_mirror
+#undef WUNET_DPP_ADD
+    return v;
+}
 // 16-byte staging registers are the NATIVE vector type: arrays of HIP's float4 struct carried across loop
 // iterations were demoted to scratch memory by hipcc (global_load -> vmcnt(0) -> scratch_store), which
 // silently serialised the software pipeline.

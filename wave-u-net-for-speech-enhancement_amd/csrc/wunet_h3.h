@@ -198,6 +198,18 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
     if (A.stats && !split) __syncthreads();       // the W tile's LDS is reused for the statistics hand-over
     const int bo = b + lseg;
     float amax = 0.0f;
+    // per-row constants in ONE batch of loads (loaded row by row, each was waited for with vmcnt(0) - together with the previous
+    // row's store: 4*M_REP serialised round trips per block)
+    float bvs[M_REP][4], eas[M_REP][4], ess[M_REP][4];
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = (mt0 + mt) * 16 + q * 4 + r;
+            bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+            eas[mt][r] = (A.xrows && co < A.Cout) ? A.ev_a[co] : 0.0f;
+            ess[mt][r] = (A.xrows && co < A.Cout) ? A.ev_s[co] : 0.0f;
+        }
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = (mt0 + mt) * 16 + q * 4 + r;
-            const float bv = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+            const float bv = bvs[mt][r];
             wunet_f4 o;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
             if (co < A.Cout && bo < A.B) {
                 wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
                 if (A.xrows) {
-                    const float ea = A.ev_a[co], es = A.ev_s[co];
+                    const float ea = eas[mt][r], es = ess[mt][r];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
                 }
@@ -226,11 +238,8 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
         if (A.stats && !split) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    s1[r] += wunet_shfl_xor(s1[r], m);
-                    s2[r] += wunet_shfl_xor(s2[r], m);
-                }
+                s1[r] = wunet_row16_sum(s1[r]);
+                s2[r] = wunet_row16_sum(s2[r]);
                 if (i16 == 0) {                                   // per-wave sums of row mt*16 + q*4 + r -> LDS
                     float* rp = reinterpret_cast<float*>(ws) + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
                     rp[0] = s1[r];
@@ -428,6 +437,16 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3p_kernel(ConvH3Ar
     wunet_setprio(0);
     if ((A.stats && !split) || A.xrows) __syncthreads();
     float amax = 0.0f;
+    float bvs[M_REP][4], eas[M_REP][4], ess[M_REP][4];     // (one batch of loads, see conv_h3_kernel)
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = (mt0 + mt) * 16 + q * 4 + r;
+            bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+            eas[mt][r] = (A.xrows && co < A.Cout) ? A.ev_a[co] : 0.0f;
+            ess[mt][r] = (A.xrows && co < A.Cout) ? A.ev_s[co] : 0.0f;
+        }
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -435,7 +454,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3p_kernel(ConvH3Ar
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int co = (mt0 + mt) * 16 + q * 4 + r;
-            const float bv = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+            const float bv = bvs[mt][r];
             wunet_f4 o;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3p_kernel(ConvH3Ar
             if (co < A.Cout && b < A.B) {
                 wunet_st4(outp + ((size_t)b * A.Cout + co) * L + l, o);
                 if (A.xrows) {
-                    const float ea = A.ev_a[co], es = A.ev_s[co];
+                    const float ea = eas[mt][r], es = ess[mt][r];
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
                 }
@@ -456,11 +475,8 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3p_kernel(ConvH3Ar
         if (A.stats && !split) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    s1[r] += wunet_shfl_xor(s1[r], m);
-                    s2[r] += wunet_shfl_xor(s2[r], m);
-                }
+                s1[r] = wunet_row16_sum(s1[r]);
+                s2[r] = wunet_row16_sum(s2[r]);
                 if (i16 == 0) {
                     float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
                     rp[0] = s1[r];

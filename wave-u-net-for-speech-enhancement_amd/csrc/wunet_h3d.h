@@ -165,7 +165,6 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
-
         for (int st = st_beg; st < nstage; ++st) {
             const int ch = st / NTG, tg = st - ch * NTG;
             const bool last = st + 1 == nstage, has_next = !last || more;
@@ -233,6 +232,19 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
         const int bo = b + lseg;
         float amax = 0.0f;
+        // the per-row constants in ONE batch of loads: loaded where they are used, each load was waited for with vmcnt(0) - i.e.
+        // together with the previous row's store - and the 4*M_REP serialised round trips were a third of a shallow layer's block
+        // time (phase stamps, tools/conv_bench.py --trace)
+        float bvs[M_REP][4], eas[M_REP][4], ess[M_REP][4];
+#pragma unroll
+        for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (mt0 + mt) * 16 + q * 4 + r;
+                bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+                eas[mt][r] = (A.xrows && co < A.Cout) ? A.ev_a[co] : 0.0f;
+                ess[mt][r] = (A.xrows && co < A.Cout) ? A.ev_s[co] : 0.0f;
+            }
 #pragma unroll
         for (int mt = 0; mt < M_REP; ++mt) {
             float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
-                const float bv = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+                const float bv = bvs[mt][r];
                 wunet_f4 o;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
                 if (co < A.Cout && bo < A.B) {
                     wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
                     if (A.xrows) {
-                        const float ea = A.ev_a[co], es = A.ev_s[co];
+                        const float ea = eas[mt][r], es = ess[mt][r];
 #pragma unroll
                         for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
                     }
@@ -261,11 +273,8 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             if (A.stats && !split) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) {
-                        s1[r] += wunet_shfl_xor(s1[r], m);
-                        s2[r] += wunet_shfl_xor(s2[r], m);
-                    }
+                    s1[r] = wunet_row16_sum(s1[r]);
+                    s2[r] = wunet_row16_sum(s2[r]);
                     if (i16 == 0) {                               // per-wave sums of row mt*16 + q*4 + r -> LDS
                         float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
                         rp[0] = s1[r];

@@ -142,6 +142,15 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
 #undef WUNET_PREFETCH
 
     // ---- epilogue: bias, store, per-channel partial statistics of the bias-free conv
+    // (the biases in ONE batch of loads: loaded at their use, each was waited for with vmcnt(0) - together with the stores before it)
+    float bvs[M_REP][4];
+#pragma unroll
+    for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int co = (mt0 + mt) * 16 + q * 4 + r;
+            bvs[mt][r] = (A.bias && co < A.Cout) ? A.bias[co] : 0.0f;
+        }
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt) {
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -156,17 +165,14 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
                 s1[r] += v;
                 s2[r] += v * v;
                 if (co < A.Cout && b < A.B)
-                    outp[((size_t)b * A.Cout + co) * L + l] = v + (A.bias ? A.bias[co] : 0.0f);
+                    outp[((size_t)b * A.Cout + co) * L + l] = v + bvs[mt][r];
             }
         }
         if (A.stats) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int m = 1; m < 16; m <<= 1) {
-                    s1[r] += wunet_shfl_xor(s1[r], m);
-                    s2[r] += wunet_shfl_xor(s2[r], m);
-                }
+                s1[r] = wunet_row16_sum(s1[r]);
+                s2[r] = wunet_row16_sum(s2[r]);
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
                 if (i16 == 0 && co < A.Cout) {
                     // [channel][row][2]: the finalize kernel then reads each channel's rows contiguously
