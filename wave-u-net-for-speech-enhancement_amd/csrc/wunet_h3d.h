@@ -50,12 +50,18 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     // RUN of 64 consecutive pieces; the runs of the x image ([plane][4 groups][COLS, de-interleaved]: RP runs per plane) are dealt
     // so that the plane of an instruction is a compile-time constant: instruction it < NPL*XF covers runs 4 (it % XF) + wave of
     // plane it / XF, the XR left-over runs of every plane share one last instruction (wave -> plane wave / XR, run 4 XF + wave % XR).
-    // Piece p of a plane is (channel group c8 = p / COLS, column col = 4 (w % Q4) + w / Q4 with w = p % COLS - the de-interleave);
-    // xmeta = c8 | item of the tile << 4 | (sample - l0 + 8) << 12 | plane << 28, or -1 for an idle wave of the last instruction.
+    // Piece p of a plane is (channel group c8 = p / COLS, column col = 4 (w % Q4) + w / Q4 with w = p % COLS - the de-interleave).
+    // Kept per piece: xoffb = bytes from the first sample of the tile in the chunk's first channel group; per thread, one bit per
+    // piece: m_live (the wave has a run in the shared instruction), m_lo / m_hi (the piece is left / right halo: outside the item
+    // for the first / last tile of an item, always for NSEG > 1), m_pl (plane of the shared instruction); c8pk / segpk = the
+    // piece's channel group (2 bits) / item of the tile (4 bits).
     constexpr int RP = 4 * COLS / 64, XF = RP / 4, XR = RP % 4;
     constexpr int XIT = NPL * XF + (XR ? 1 : 0);
     static_assert(XR * NPL <= 4, "left-over runs fit one instruction");
-    int xmeta[XIT];
+    static_assert(XIT <= 16, "descriptor bit fields");
+    int xoffb[XIT];
+    unsigned m_live = 0, m_lo = 0, m_hi = 0, m_pl = 0, c8pk = 0;
+    unsigned long long segpk = 0;
     int xrun = 0;                                   // run (within its plane) of this wave in the last, shared instruction
 #pragma unroll
     for (int it = 0; it < XIT; ++it) {
@@ -64,7 +70,13 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         if (it == NPL * XF) { pl = wave / (XR ? XR : 1); run = 4 * XF + wave % (XR ? XR : 1); live = wave < XR * NPL; xrun = run; }
         const int p = run * 64 + lane, c8 = p / COLS, w = p % COLS;
         const int col = 4 * (w % Q4) + w / Q4, seg = col / SW, lrel = col - seg * SW - 8;
-        xmeta[it] = live ? (c8 | (seg << 4) | ((lrel + 8) << 12) | (pl << 28)) : -1;
+        xoffb[it] = ((seg * A.C8 + c8) * L + lrel) * 16;
+        m_live |= (unsigned)live << it;
+        m_lo |= (unsigned)(lrel < 0) << it;
+        m_hi |= (unsigned)(lrel >= LSEG) << it;
+        m_pl |= (unsigned)(pl & 1) << it;
+        c8pk |= (unsigned)c8 << (2 * it);
+        segpk |= (unsigned long long)seg << (4 * it);
     }
     // W sub-tile [hi|lo][M_REP][TG][64 pieces]: piece f = tid + 256 it; woff = halfs from the stage's first piece in the pack | lo << 30
     int woff[WIT];
@@ -77,28 +89,44 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     const wunet_lds_t xs_a = wunet_lds_addr(xs), ws_a = wunet_lds_addr(ws);
     const int wave_u = wunet_uniform(wave);
     const long long zero_a = (long long)reinterpret_cast<size_t>(zero);
-    // (the descriptors are made opaque at every use: hipcc would otherwise hoist one 64-bit address per piece out of the stage
-    // loop and carry 34 more registers through the MFMA phase; the selects are arithmetic so that the issue stays ONE basic block)
-#define WUNET_H3D_X_PIECE(IT_, B_, L0_, CH_, XH_, XL_)                                                            \
+    // pieces of the tile that lie inside the tensor: bit per piece.  Halo pieces of an item's first / last tile (every halo piece
+    // for NSEG > 1: each item of the tile carries its own zero padding), items beyond the batch, channel groups beyond C8 (only the
+    // last chunk can have them: the test is skipped elsewhere)
+#define WUNET_H3D_VALID(B_, L0_, CH_, OUT_)                                                                       \
+    unsigned OUT_ = m_live;                                                                                       \
     {                                                                                                             \
-        int m_ = xmeta[IT_];                                                                                      \
-        wunet_opaque(m_);                                                                                         \
-        const int c8_ = m_ & 15, seg_ = (m_ >> 4) & 255, lrel_ = ((m_ >> 12) & 0xffff) - 8;                       \
-        const bool ok_ = (CH_) * 4 + c8_ < A.C8 && (unsigned)((L0_) + lrel_) < (unsigned)L && (B_) + seg_ < A.B;  \
-        const int off_ = ((seg_ * A.C8 + c8_) * L + lrel_) * 16;                                                  \
-        const long long real_ = ((IT_) < NPL * XF ? ((IT_) / XF ? (XL_) : (XH_)) : (((m_ >> 28) & 1) ? (XL_) : (XH_))) + off_; \
-        const long long a_ = zero_a + ((real_ - zero_a) & -(long long)ok_);                                       \
+        if (NSEG > 1 || (L0_) == 0) OUT_ &= ~m_lo;                                                                \
+        if (NSEG > 1 || (L0_) + 256 >= L) OUT_ &= ~m_hi;                                                          \
+        if (NSEG > 1 && (B_) + NSEG > A.B) {                                                                      \
+            _Pragma("unroll") for (int it = 0; it < XIT; ++it)                                                    \
+                if ((B_) + (int)((segpk >> (4 * it)) & 15) >= A.B) OUT_ &= ~(1u << it);                           \
+        }                                                                                                         \
+        if ((CH_) * 4 + 4 > A.C8) {                                                                               \
+            _Pragma("unroll") for (int it = 0; it < XIT; ++it)                                                    \
+                if ((CH_) * 4 + (int)((c8pk >> (2 * it)) & 3) >= A.C8) OUT_ &= ~(1u << it);                       \
+        }                                                                                                         \
+    }
+    // (the descriptors are made opaque at every use: hipcc would otherwise hoist one 64-bit address per piece out of the stage
+    // loop and carry 34 more registers through the MFMA phase)
+#define WUNET_H3D_X_PIECE(IT_, VALID_, XH_, XL_)                                                                  \
+    {                                                                                                             \
+        int o_ = xoffb[IT_];                                                                                      \
+        wunet_opaque(o_);                                                                                         \
+        const bool lo_ = (IT_) < NPL * XF ? (IT_) / XF != 0 : ((m_pl >> (IT_)) & 1) != 0;                         \
+        const long long real_ = (lo_ ? (XL_) : (XH_)) + o_;                                                       \
+        const long long a_ = ((VALID_) >> (IT_)) & 1 ? real_ : zero_a;                                            \
         const int run_ = (IT_) < NPL * XF ? 4 * ((IT_) % XF) + wave_u : wunet_uniform(xrun);                      \
-        const int pl_ = (IT_) < NPL * XF ? (IT_) / XF : wunet_uniform((m_ >> 28) & 1);                            \
+        const int pl_ = (IT_) < NPL * XF ? (IT_) / XF : wunet_uniform((m_pl >> (IT_)) & 1);                       \
         wunet_dma16a(reinterpret_cast<const void*>(a_), xs_a + (pl_ * 4 * COLS + run_ * 64) * 16);                \
     }
 #define WUNET_H3D_ISSUE_X(B_, L0_, CH_)                                                                           \
     {                                                                                                             \
         const long long boff_ = (long long)((((size_t)(B_) * A.C8 + (CH_) * 4) * L + (L0_)) * 16);                \
         const long long xh_ = (long long)reinterpret_cast<size_t>(A.xh) + boff_, xl_ = (long long)reinterpret_cast<size_t>(A.xl) + boff_; \
+        WUNET_H3D_VALID(B_, L0_, CH_, valid_)                                                                     \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
-            if (it < NPL * XF) WUNET_H3D_X_PIECE(it, B_, L0_, CH_, xh_, xl_)                                      \
-            else if (xmeta[it] >= 0) WUNET_H3D_X_PIECE(it, B_, L0_, CH_, xh_, xl_)                                \
+            if (it < NPL * XF) WUNET_H3D_X_PIECE(it, valid_, xh_, xl_)                                            \
+            else if ((m_live >> it) & 1) WUNET_H3D_X_PIECE(it, valid_, xh_, xl_)                                  \
         }                                                                                                         \
     }
 #define WUNET_H3D_ISSUE_W(MT0_, CH_, TG_)                                                                         \
@@ -109,8 +137,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             if ((it + 1) * WUNET_THREADS <= WP || tid + it * WUNET_THREADS < WP) {                                \
                 int m_ = woff[it];                                                                                \
                 wunet_opaque(m_);                                                                                 \
-                const long long sel_ = -(long long)((m_ >> 30) & 1);                                              \
-                const long long a_ = wh_ + ((wl_ - wh_) & sel_) + (long long)(m_ & 0x3fffffff) * 2;               \
+                const long long a_ = ((m_ >> 30) & 1 ? wl_ : wh_) + (long long)(m_ & 0x3fffffff) * 2;             \
                 wunet_dma16a(reinterpret_cast<const void*>(a_), ws_a + (it * WUNET_THREADS + wave_u * 64) * 16);  \
             }                                                                                                     \
         }                                                                                                         \
@@ -232,57 +259,69 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
         const int bo = b + lseg;
         float amax = 0.0f;
-        // the per-row constants in ONE batch of loads: loaded where they are used, each load was waited for with vmcnt(0) - i.e.
-        // together with the previous row's store - and the 4*M_REP serialised round trips were a third of a shallow layer's block
-        // time (phase stamps, tools/conv_bench.py --trace)
-        float bvs[M_REP][4], eas[M_REP][4], ess[M_REP][4];
+        // the per-row constants in ONE batch of loads: loaded row by row where they are used, each load was waited for with
+        // vmcnt(0) - i.e. together with the previous row's store - and the 4*M_REP serialised round trips were a third of a shallow
+        // layer's block time (phase stamps, tools/conv_bench.py --trace)
+        float bvs[M_REP][4];
 #pragma unroll
         for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
                 bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
-                eas[mt][r] = (A.xrows && co < A.Cout) ? A.ev_a[co] : 0.0f;
-                ess[mt][r] = (A.xrows && co < A.Cout) ? A.ev_s[co] : 0.0f;
             }
-#pragma unroll
-        for (int mt = 0; mt < M_REP; ++mt) {
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-            const int l = l0 + ll0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int co = (mt0 + mt) * 16 + q * 4 + r;
-                const float bv = bvs[mt][r];
-                wunet_f4 o;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    const float vv = acc[mt][nt][r] * inv * inv2;
-                    s1[r] += vv;
-                    s2[r] += vv * vv;
-                    o[nt] = vv + bv;
-                }
-                if (co < A.Cout && bo < A.B) {
-                    wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
-                    if (A.xrows) {
-                        const float ea = eas[mt][r], es = ess[mt][r];
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
-                    }
-                }
-            }
-            if (A.stats && !split) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    s1[r] = wunet_row16_sum(s1[r]);
-                    s2[r] = wunet_row16_sum(s2[r]);
-                    if (i16 == 0) {                               // per-wave sums of row mt*16 + q*4 + r -> LDS
-                        float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
-                        rp[0] = s1[r];
-                        rp[1] = s2[r];
-                    }
-                }
-            }
-        }
+        // row (mt, r) of this lane: prow + (mt * 16 + r) * L  (uniform strides: no 64-bit multiply per row)
+        float* const prow = outp + ((size_t)bo * A.Cout + mt0 * 16 + q * 4) * L + (l0 + ll0);
+        const bool want_stats = A.stats && !split;
+        const bool full = (mt0 + M_REP) * 16 <= A.Cout && (NSEG == 1 || b + NSEG <= A.B);     // no row / item of the tile outside the tensor
+        // STATS_: Sigma, Sigma^2 of the bias-free conv per row; GUARD_: rows beyond Cout / items beyond B exist; EVAL_: the activation
+        // bound of eval mode.  Copies of the loop behind uniform branches: the un-guarded, statistics-free one (data gradients, K
+        // splits) is half the instructions
+#define WUNET_H3D_ROWS(STATS_, GUARD_, EVAL_)                                                                     \
+    float eas[M_REP][4], ess[M_REP][4];                                                                           \
+    if (EVAL_) {                                                  /* one batch of loads, like the biases */      \
+        _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+                const int co = (mt0 + mt) * 16 + q * 4 + r;                                                       \
+                eas[mt][r] = co < A.Cout ? A.ev_a[co] : 0.0f;                                                     \
+                ess[mt][r] = co < A.Cout ? A.ev_s[co] : 0.0f;                                                     \
+            }                                                                                                     \
+    }                                                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
+            const int co = (mt0 + mt) * 16 + q * 4 + r;                                                           \
+            const float bv = bvs[mt][r];                                                                          \
+            wunet_f4 o;                                                                                           \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
+                const float vv = acc[mt][nt][r] * inv * inv2;                                                     \
+                if (STATS_) { s1[r] += vv; s2[r] += vv * vv; }                                                    \
+                o[nt] = vv + bv;                                                                                  \
+            }                                                                                                     \
+            if (!(GUARD_) || (co < A.Cout && bo < A.B)) {                                                         \
+                wunet_st4(prow + (size_t)(mt * 16 + r) * L, o);                                                   \
+                if (EVAL_) {                                                                                      \
+                    const float ea = eas[mt][r], es = ess[mt][r];                                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));  \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (STATS_) {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+                s1[r] = wunet_row16_sum(s1[r]);                                                                   \
+                s2[r] = wunet_row16_sum(s2[r]);                                                                   \
+                if (i16 == 0) {                               /* per-wave sums of row mt*16 + q*4 + r -> LDS */   \
+                    float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;                                 \
+                    rp[0] = s1[r];                                                                                \
+                    rp[1] = s2[r];                                                                                \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+        if (A.xrows) { WUNET_H3D_ROWS(false, true, true) }          // eval mode: the maximum of the activation bound instead of statistics
+        else if (want_stats) { if (full) { WUNET_H3D_ROWS(true, false, false) } else { WUNET_H3D_ROWS(true, true, false) } }
+        else { if (full) { WUNET_H3D_ROWS(false, false, false) } else { WUNET_H3D_ROWS(false, true, false) } }
+#undef WUNET_H3D_ROWS
         if (A.xrows) {                            // eval: block maximum of the activation bound (max is order independent)
 #pragma unroll
             for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
