@@ -18,5 +18,8 @@ int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim
 {
     WUNET_XCASE(15, 2, 1) WUNET_XCASE(15, 3, 1) WUNET_XCASE(15, 4, 1)
     WUNET_XCASE(5, 2, 1) WUNET_XCASE(5, 3, 1) WUNET_XCASE(5, 4, 1)
+    WUNET_XCASE(15, 2, 2) WUNET_XCASE(15, 3, 2) WUNET_XCASE(5, 2, 2) WUNET_XCASE(5, 3, 2)
+    WUNET_XCASE(15, 2, 4) WUNET_XCASE(15, 3, 4) WUNET_XCASE(5, 2, 4) WUNET_XCASE(5, 3, 4)
+    WUNET_XCASE(15, 2, 8) WUNET_XCASE(15, 3, 8) WUNET_XCASE(5, 2, 8) WUNET_XCASE(5, 3, 8)
     return -1;
 }

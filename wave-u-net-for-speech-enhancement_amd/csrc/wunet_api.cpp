@@ -569,11 +569,13 @@ bool h3_conv_is_paired(int B, int L)
     return pair_env && L >= 256 && (posn & 511) == 0;
 }
 
-// conv_h3d_kernel (DMA-staged, pipelined, persistent) runs instead of conv_h3_kernel: un-segmented tiles (L >= 256)
+// conv_h3d_kernel (DMA-staged, pipelined, persistent) runs instead of conv_h3_kernel: every tile shape but the 16-sample level's
+// (16 items per tile: its x image alone is 64 KB)
 bool h3_conv_is_dma(int L)
 {
-    const char* e = getenv("WUNET_H3_XDMA");            // A/B switch (read per launch: tests toggle it)
-    return L >= 256 && !(e && atoi(e) == 0);
+    const char* e = getenv("WUNET_H3_XDMA");            // A/B switch (read per launch: tests toggle it): 0 = off, 2 = un-segmented tiles only
+    const int v = e ? atoi(e) : 1;
+    return v != 0 && L >= (v == 2 ? 256 : 32);
 }
 
 // resident conv_h3d blocks the grid is sized for: two per CU (its launch bounds); WUNET_H3_GRID overrides (tests: a few blocks walk

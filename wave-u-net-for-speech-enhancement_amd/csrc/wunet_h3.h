@@ -223,7 +223,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
             for (int nt = 0; nt < 4; ++nt) {
                 const float v = acc[mt][nt][r] * inv * inv2;
                 s1[r] += v;
-                s2[r] += v * v;
+                s2[r] = fmaf(v, v, s2[r]);
                 o[nt] = v + bv;
             }
             if (co < A.Cout && bo < A.B) {
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3p_kernel(ConvH3Ar
             for (int nt = 0; nt < 4; ++nt) {
                 const float v = acc[mt][nt][r] * inv * inv2;
                 s1[r] += v;
-                s2[r] += v * v;
+                s2[r] = fmaf(v, v, s2[r]);
                 o[nt] = v + bv;
             }
             if (co < A.Cout && b < A.B) {

@@ -295,7 +295,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             wunet_f4 o;                                                                                           \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
                 const float vv = acc[mt][nt][r] * inv * inv2;                                                     \
-                if (STATS_) { s1[r] += vv; s2[r] += vv * vv; }                                                    \
+                if (STATS_) { s1[r] += vv; s2[r] = fmaf(vv, vv, s2[r]); }                                                    \
                 o[nt] = vv + bv;                                                                                  \
             }                                                                                                     \
             if (!(GUARD_) || (co < A.Cout && bo < A.B)) {                                                         \

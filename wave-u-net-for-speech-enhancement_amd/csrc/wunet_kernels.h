@@ -163,7 +163,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_mfma_kernel(ConvArgs A)
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
                 const float v = acc[mt][nt][r];
                 s1[r] += v;
-                s2[r] += v * v;
+                s2[r] = fmaf(v, v, s2[r]);
                 if (co < A.Cout && b < A.B)
                     outp[((size_t)b * A.Cout + co) * L + l] = v + bvs[mt][r];
             }
