@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--layers", default="")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--min-l", type=int, default=256)
+    ap.add_argument("--what", choices=["conv", "wgrad"], default="conv", help="conv: forward + data gradient kernels; wgrad: weight gradient kernels")
     ap.add_argument("cfgs", nargs="*", default=[""])
     a = ap.parse_args()
     lib = importlib.import_module(PKG + "._lib").load_hip()
@@ -70,6 +71,7 @@ def main():
         gz = torch.randn(B, cout, L, device=dev, generator=g)
         z = torch.empty(B, cout, L, device=dev)
         dx = torch.empty(B, cin, L, device=dev)
+        dw = torch.empty(cout, cin, K, device=dev)
         cells, ref = [], None
         for ci_, cfg in enumerate(a.cfgs):
             saved = {}
@@ -79,20 +81,28 @@ def main():
                 os.environ[k] = v
 
             def run():
+                if a.what == "wgrad":
+                    assert lib.wunet_op_conv1d_wgrad_split(gz.data_ptr(), x.data_ptr(), dw.data_ptr(), B, cin, cout, L, K, None) == 0, lib.wunet_last_error()
+                    return
                 assert lib.wunet_op_conv1d_split(x.data_ptr(), w.data_ptr(), b.data_ptr(), z.data_ptr(), B, cin, cout, L, K, None) == 0, lib.wunet_last_error()
                 assert lib.wunet_op_conv1d_dgrad_split(gz.data_ptr(), w.data_ptr(), dx.data_ptr(), B, cin, cout, L, K, None) == 0, lib.wunet_last_error()
             rows = profiled(lib, run, a.reps)
             torch.cuda.synchronize()
-            res = (z.clone(), dx.clone())
+            res = (dw.clone(), dw.clone()) if a.what == "wgrad" else (z.clone(), dx.clone())
             if ref is None:
                 ref = res
                 same = ""
             else:
                 same = "=" if (torch.equal(ref[0], res[0]) and torch.equal(ref[1], res[1])) else "DIFF"
-            ks = [(k, v) for k, v in rows.items() if k.startswith("conv_h3")]
-            # forward and data gradient may share one instantiation: the profile merges them, so report the sum of both launches
-            us = sum(v[0] * (2 if len(ks) == 1 else 1) for _, v in ks)
-            fl = 2.0 * 2.0 * B * L * cin * cout * K
+            if a.what == "wgrad":
+                ks = [(k, v) for k, v in rows.items() if k.startswith("wgrad_h3") and "reduce" not in k]
+                us = sum(v[0] for _, v in ks)
+                fl = 2.0 * B * L * cin * cout * K
+            else:
+                ks = [(k, v) for k, v in rows.items() if k.startswith("conv_h3")]
+                # forward and data gradient may share one instantiation: the profile merges them, so report the sum of both launches
+                us = sum(v[0] * (2 if len(ks) == 1 else 1) for _, v in ks)
+                fl = 2.0 * 2.0 * B * L * cin * cout * K
             tot[ci_][0] += us
             tot[ci_][1] += fl
             cells.append("%7.1f us %4.0f TF %-4s %-12s" % (us, fl / us / 1e6, same, ",".join(k.split("kernel")[1] for k, _ in ks)[:12]))

@@ -71,8 +71,22 @@ int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, in
         return 0;                                                                                          \
     }
 
-int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st, bool bf)
+#define WUNET_D64CASE(T, M)                                                                                \
+    if (tp == 64 && taps == T && mrep == M && db) {                                                        \
+        if (bf) {                                                                                          \
+            if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M, true, true, 64>), smem) != 0) return -2;       \
+            WUNET_LAUNCH((wgrad_h3d_kernel<T, M, true, true, 64>), grid, dim3(WUNET_THREADS), smem, st, a); \
+        } else {                                                                                           \
+            if (WUNET_ALLOW_BIG_LDS((wgrad_h3d_kernel<T, M, true, false, 64>), smem) != 0) return -2;      \
+            WUNET_LAUNCH((wgrad_h3d_kernel<T, M, true, false, 64>), grid, dim3(WUNET_THREADS), smem, st, a); \
+        }                                                                                                  \
+        return 0;                                                                                          \
+    }
+
+int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st, bool bf, int tp)
 {
+    WUNET_D64CASE(15, 2) WUNET_D64CASE(15, 3) WUNET_D64CASE(5, 2) WUNET_D64CASE(5, 3) WUNET_D64CASE(5, 4)
+    if (tp != 128) return -1;
     WUNET_DCASE(15, 2, true) WUNET_DCASE(15, 3, true) WUNET_DCASE(15, 4, true) WUNET_DCASE(15, 5, true) WUNET_DCASE(15, 6, true)
     WUNET_DCASE(5, 2, true) WUNET_DCASE(5, 3, true) WUNET_DCASE(5, 4, true) WUNET_DCASE(5, 5, true)
     WUNET_DCASE(15, 2, false) WUNET_DCASE(15, 3, false) WUNET_DCASE(5, 2, false) WUNET_DCASE(5, 3, false) WUNET_DCASE(5, 4, false)

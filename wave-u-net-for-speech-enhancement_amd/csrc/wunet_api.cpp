@@ -391,11 +391,14 @@ void plan_h3_wgrad(LayerPlan& l, int B)
     // alone (one block per CU, it waits on its staging), but with its 87 KB of LDS only one conv_h3 block fits
     // beside it and the whole step (weight gradients run concurrently with the data-gradient chain) is slower:
     // 6.76 vs 6.68 ms.  128 unless WUNET_H3W_TP=256.
-    static const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;
+    const int tp_env = getenv("WUNET_H3W_TP") ? atoi(getenv("WUNET_H3W_TP")) : 128;       // (read per plan: tests / measurements toggle it)
     l.h3w_tp = tp_env == 256 ? 256 : 128;
+    // 64: double-buffered chunks of 64 positions at two blocks per CU (wgrad_h3d_kernel<.., true, .., 64>) where that kernel exists
+    const bool d64 = tp_env == 64 && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
+    if (d64) l.h3w_tp = 64;
     // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 up to 3
-    const bool sb2 = !getenv("WUNET_NO_H3W_SB") && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && l.h3w_tp == 128 &&
-                     ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
+    const bool sb2 = d64 || (!getenv("WUNET_NO_H3W_SB") && !getenv("WUNET_NO_H3W_DMA") && l.L >= 128 && l.h3w_tp == 128 &&
+                             ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3)));
     const long long slots = 256LL * ((l.h3w_mrep <= 2 || sb2) ? 2 : 1);      // resident blocks: launch bounds of the wgrad kernels
     long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
     if (ks < 1) ks = 1;
@@ -663,21 +666,21 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     // (blocks of two m-tiles keep the register-staged kernel: it runs two blocks per CU, which is worth more)
     static const bool dma = getenv("WUNET_NO_H3W_DMA") == nullptr;                // A/B switch
     const int npl = bf ? 1 : 2;
-    const size_t smem_d = (size_t)2 * (npl * (l.h3w_mrep * 2) * 132 + npl * xg * 148 + 8) * 16;
+    const size_t smem_d = (size_t)2 * (npl * (l.h3w_mrep * 2) * (tp + 4) + npl * xg * (tp + 20) + 8) * 16;
     int rc;
-    if (dma && nseg == 1 && tp == 128 && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
+    if (dma && nseg == 1 && (tp == 128 || tp == 64) && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
         WgradH3dArgs a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
         a.zero = reinterpret_cast<const wunet_half*>(zero);
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
-        snprintf(pname, sizeof pname, bf ? "wgrad_h3d_kernel<%d, %d, bf16>" : "wgrad_h3d_kernel<%d, %d>", l.taps, l.h3w_mrep);
+        snprintf(pname, sizeof pname, bf ? "wgrad_h3d_kernel<%d, %d, bf16>" : (tp == 64 ? "wgrad_h3d_kernel<%d, %d, 64>" : "wgrad_h3d_kernel<%d, %d>"), l.taps, l.h3w_mrep);
         prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
         // two blocks per CU with a single buffer where the registers allow it (two independent blocks hide each other's
         // waits: +18-28 % on those kernels), else one block with double-buffered tiles
         static const bool sb = getenv("WUNET_NO_H3W_SB") == nullptr;              // A/B switch
-        const bool db = !(sb && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3)));
-        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st, bf != 0);
+        const bool db = tp == 64 || !(sb && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3)));
+        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st, bf != 0, tp);
     } else {
         WgradH3Args a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
@@ -1194,7 +1197,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         }
         // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
         //      + deterministic reduce
-        {
+        auto weight_gradient = [&]() -> int {
             if (sd != st) {
                 if (hipEventRecord(side->ev_fork, st) != hipSuccess || hipStreamWaitEvent(sd, side->ev_fork, 0) != hipSuccess)
                     return fail(WUNET_E_RUNTIME, "fork onto the weight-gradient stream failed");
@@ -1246,7 +1249,12 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                 }
                 WUNET_CHECK_LAUNCH();
             }
-        }
+            return 0;
+        };
+        // fork point of the side stream (A/B switch WUNET_FORK_LATE=1: after this layer's data gradient is enqueued instead of
+        // before it - the weight gradient then runs beside the next layer's HBM-bound gradient assembly, not beside the other GEMM)
+        static const bool fork_late = getenv("WUNET_FORK_LATE") != nullptr;
+        if (!fork_late || i == 0) { const int rc = weight_gradient(); if (rc) return rc; }
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
         if (i > 0 && l.h3d) {
             // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
@@ -1289,6 +1297,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                 WUNET_CHECK_LAUNCH();
             }
         }
+        if (fork_late && i != 0) { const int rc = weight_gradient(); if (rc) return rc; }
     }
     // join: the caller's stream sees every weight gradient.  An un-joined range (wunet_backward_range_async) leaves them to
     // wunet_backward_join - except the range that ends the backward, which always joins: the next forward overwrites the

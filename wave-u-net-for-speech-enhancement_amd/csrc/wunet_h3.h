@@ -699,10 +699,13 @@ struct WgradH3dArgs {
     size_t part_stride;
 };
 
-template <int TAPS, int M_REP, bool DB, bool BF = false>
-__global__ __launch_bounds__(WUNET_THREADS, (DB ? 1 : 2)) void wgrad_h3d_kernel(WgradH3dArgs A)
+// TP = 64 with DB: chunks of 64 positions, double buffered within the LDS budget of ONE 128-position buffer - two blocks per CU AND
+// the DMA of chunk k+1 under the MFMAs of chunk k (the halo rows of the x image weigh 31 % instead of 16 %).
+template <int TAPS, int M_REP, bool DB, bool BF = false, int TP = 128>
+__global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wgrad_h3d_kernel(WgradH3dArgs A)
 {
-    constexpr int TP = 128, GP = TP + 4, XPOS = TP + 20;          // plane strides (pieces), both 4 mod 16
+    constexpr int GP = TP + 4, XPOS = TP + 20;                    // plane strides (pieces), both 4 mod 16
+    static_assert(TP == 128 || TP == 64, "chunk");
     constexpr int WG = TAPS == 15 ? 2 : 4;
     constexpr int TW = TAPS == 15 ? 8 : 5;
     constexpr int OB = TAPS == 15 ? 1 : 8 - TAPS / 2;
