@@ -795,32 +795,52 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
         __syncthreads();                           // chunk k has landed (vmcnt wait + barrier); nobody reads the other buffer any more
         if (DB && k + 1 < kend) WUNET_WH3D_DMA(k + 1, cur ^ 1)
         const wunet_half* gs = lds + (size_t)cur * BUF;
+        // fragments are read ONE (K step, tap) ahead of the MFMAs that use them (hipcc sinks a fragment read to its first use and
+        // waits for it with lgkmcnt(0): one LDS round trip per tap with nothing from this wave in the matrix pipe); the MFMAs of a
+        // tap are issued pass-major (per accumulator the order lo*hi, hi*lo, hi*hi is unchanged: bit-identical results)
+        constexpr int KS = TP / 32;
+        wunet_h8 ah[2][M_REP], al[2][M_REP], bh[2], bl[2];
+#define WUNET_WH3D_LOAD_A(BUF_, KS_)                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        const wunet_half* p = gs + gbase + ((mt * 2) * GP + (KS_) * 32) * 8;                                      \
+        ah[BUF_][mt] = wunet_ldtr8(p, p + 32);                                                                    \
+        if (!BF) al[BUF_][mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);                               \
+    }
+#define WUNET_WH3D_LOAD_B(BUF_, KS_, TW_)                                                                         \
+    {                                                                                                             \
+        const wunet_half* p = gs + xbase + ((KS_) * 32 + OB + (TW_)) * 8;                                         \
+        bh[BUF_] = wunet_ldtr8(p, p + 32);                                                                        \
+        if (!BF) bl[BUF_] = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);                               \
+    }
+        WUNET_WH3D_LOAD_A(0, 0)
+        WUNET_WH3D_LOAD_B(0, 0, 0)
 #pragma unroll
-        for (int ks = 0; ks < TP / 32; ++ks) {
-            wunet_h8 ah[M_REP], al[M_REP];
-#pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt) {
-                const wunet_half* p = gs + gbase + ((mt * 2) * GP + ks * 32) * 8;
-                ah[mt] = wunet_ldtr8(p, p + 32);
-                if (!BF) al[mt] = wunet_ldtr8(p + GG * GP * 8, p + GG * GP * 8 + 32);
-            }
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int tw = 0; tw < TW; ++tw) {
-                const wunet_half* p = gs + xbase + (ks * 32 + OB + tw) * 8;
-                const wunet_h8 bh = wunet_ldtr8(p, p + 32);
-                wunet_h8 bl = bh;
-                if (!BF) bl = wunet_ldtr8(p + XG * XPOS * 8, p + XG * XPOS * 8 + 32);
+                const int sb = (ks * TW + tw) & 1, ab = ks & 1;
+                if (tw + 1 < TW) {
+                    if (sb) { WUNET_WH3D_LOAD_B(0, ks, tw + 1) } else { WUNET_WH3D_LOAD_B(1, ks, tw + 1) }
+                } else if (ks + 1 < KS) {
+                    if (ab) { WUNET_WH3D_LOAD_A(0, ks + 1) } else { WUNET_WH3D_LOAD_A(1, ks + 1) }
+                    if (sb) { WUNET_WH3D_LOAD_B(0, ks + 1, 0) } else { WUNET_WH3D_LOAD_B(1, ks + 1, 0) }
+                }
+                wunet_sched_fence();
+                if (BF) {
 #pragma unroll
-                for (int mt = 0; mt < M_REP; ++mt) {
-                    if (BF) acc[mt][tw] = wunet_mfma16b(ah[mt], bh, acc[mt][tw]);
-                    else {
-                        acc[mt][tw] = wunet_mfma16h(al[mt], bh, acc[mt][tw]);
-                        acc[mt][tw] = wunet_mfma16h(ah[mt], bl, acc[mt][tw]);
-                        acc[mt][tw] = wunet_mfma16h(ah[mt], bh, acc[mt][tw]);
-                    }
+                    for (int mt = 0; mt < M_REP; ++mt) acc[mt][tw] = wunet_mfma16b(ah[ab][mt], bh[sb], acc[mt][tw]);
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < M_REP; ++mt) acc[mt][tw] = wunet_mfma16h(al[ab][mt], bh[sb], acc[mt][tw]);
+#pragma unroll
+                    for (int mt = 0; mt < M_REP; ++mt) acc[mt][tw] = wunet_mfma16h(ah[ab][mt], bl[sb], acc[mt][tw]);
+#pragma unroll
+                    for (int mt = 0; mt < M_REP; ++mt) acc[mt][tw] = wunet_mfma16h(ah[ab][mt], bh[sb], acc[mt][tw]);
                 }
             }
         }
+#undef WUNET_WH3D_LOAD_A
+#undef WUNET_WH3D_LOAD_B
     }
 #undef WUNET_WH3D_DMA
 
