@@ -248,6 +248,7 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipGetLastError() { return 0; }
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2
+#define hipEventDisableSystemFence 0x20000000
 inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)1; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }

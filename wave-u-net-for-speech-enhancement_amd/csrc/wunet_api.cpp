@@ -706,9 +706,12 @@ wunet_ctx::Side* side_for_current_device(wunet_ctx* c)
     auto it = c->side.find(dev);
     if (it != c->side.end()) return &it->second;
     wunet_ctx::Side sd;
+    // both streams live on one device: device-scope release at the fork / join events is enough (WUNET_EVENT_SYSFENCE=1: the default
+    // system-scope fence, for A/B measurements)
+    const unsigned evf = hipEventDisableTiming | (getenv("WUNET_EVENT_SYSFENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
     if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&sd.ev_fork, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ev_join, evf) != hipSuccess) {
         fail(WUNET_E_RUNTIME, "cannot create the side stream of device %d", dev);
         return nullptr;
     }
