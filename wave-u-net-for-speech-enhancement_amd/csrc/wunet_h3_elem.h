@@ -344,6 +344,9 @@ struct PrepH3Args {
 // 689 -> 523 us of operand passes per step, 6.36 -> 6.19 ms.  The same change to gz_split_h3_kernel, which reads twice
 // what it writes, measured 0.4 % slower and was dropped.)
 // MODE (compile time): 0 decimate, 1 decimate + skip destination, 2 upsample (+) skip concat, 3 upsample only.
+// Every load of an iteration is issued before the first value is used (clamped indices instead of branches around loads, the
+// conversion in a second phase): written with `if (c < C)` around each element's load, hipcc put one s_waitcnt vmcnt(0) per
+// element - 8 to 24 serialised memory round trips per thread and iteration.
 template <int MODE>
 __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
 {
@@ -364,24 +367,50 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
         int i0 = 0, i1 = 0;
         float l0 = 0.0f, l1 = 0.0f;
         if (KIND != 0) wunet_up_coord(p, Lh, A.up_scale, i0, i1, l0, l1);     // once for the 8 channels
+        // skip half of the decoder input at the producer's resolution (SKIP_DST): the wave's 64 samples p0 .. p0+63 come from the
+        // 128 source samples 2*p0 .. 2*p0+127; this lane activates and writes source samples 2*p0+lane and 2*p0+64+lane
+        // (lane-contiguous again).  Rows shorter than a wave: the thread's own pair 2p, 2p+1.
+        const int lane = (int)(threadIdx.x & 63);
+        const int q0 = A.L >= 64 ? 2 * (p - lane) + lane : 2 * p;
+        const int qstep = A.L >= 64 ? 64 : 1;
+        // ---- phase 1: every load of the iteration
+        float za[8], zb[8], av[8], sv[8], zq[2][8];
+        bool from_up[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            const int cc = c < C ? c : C - 1;                // (values of channels beyond C are zeroed below)
+            from_up[e] = true;
+            if (KIND == 0) {
+                const float* zr = A.z0 + ((size_t)b * A.C0 + cc) * (size_t)(2 * A.L);
+                za[e] = zr[2 * p];
+                zb[e] = 0.0f;
+                av[e] = A.a0[cc]; sv[e] = A.s0[cc];
+                if (SKIP_DST) { zq[0][e] = zr[q0]; zq[1][e] = zr[q0 + qstep]; }
+            } else {
+                const bool up = UP_ONLY || cc < A.C0;
+                from_up[e] = up;
+                const int cu = up ? cc : 0, cs = up ? 0 : cc - A.C0;
+                const float* zr = up ? A.z0 + ((size_t)b * A.C0 + cu) * Lh : A.z1 + ((size_t)b * A.C1 + cs) * A.L;
+                za[e] = zr[up ? i0 : p];
+                zb[e] = zr[up ? i1 : p];
+                av[e] = up ? A.a0[cu] : A.a1[cs];
+                sv[e] = up ? A.s0[cu] : A.s1[cs];
+            }
+        }
+        // ---- phase 2: activate, scale, split, store
         {
             wunet_h8 h, l;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = c8 * 8 + e;
-                float v = 0.0f;
-                if (c < C) {
-                    if (KIND == 0) {
-                        v = wunet_lrelu(A.a0[c] * A.z0[((size_t)b * A.C0 + c) * (size_t)(2 * A.L) + 2 * p] + A.s0[c]);
-                    } else if (UP_ONLY || c < A.C0) {
-                        const float a = A.a0[c], s = A.s0[c];
-                        const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
-                        v = l0 * wunet_lrelu(a * zr[i0] + s) + l1 * wunet_lrelu(a * zr[i1] + s);
-                    } else {
-                        const int cs = c - A.C0;
-                        v = wunet_lrelu(A.a1[cs] * A.z1[((size_t)b * A.C1 + cs) * A.L + p] + A.s1[cs]);
-                    }
+                float v;
+                if (KIND == 0) v = wunet_lrelu(av[e] * za[e] + sv[e]);
+                else {
+                    const float u0 = wunet_lrelu(av[e] * za[e] + sv[e]), u1 = wunet_lrelu(av[e] * zb[e] + sv[e]);
+                    v = from_up[e] ? l0 * u0 + l1 * u1 : u0;
                 }
+                if (c >= C) v = 0.0f;
                 wunet_half a, d;
                 wunet_split_rt(A.bf, xs_ * v, a, d);
                 wunet_put_half(h, e, a);
@@ -391,12 +420,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
             if (!A.bf) wunet_sth8(A.xl + (row * A.L + (size_t)p) * 8, l);
         }
         if (SKIP_DST) {
-            // skip half of the decoder input at the producer's resolution: the wave's 64 samples p0 .. p0+63 come from the
-            // 128 source samples 2*p0 .. 2*p0+127; this lane activates and writes source samples 2*p0+lane and 2*p0+64+lane
-            // (lane-contiguous again).  Rows shorter than a wave: the thread's own pair 2p, 2p+1.
-            const int lane = (int)(threadIdx.x & 63);
-            const int q0 = A.L >= 64 ? 2 * (p - lane) + lane : 2 * p;
-            const int qstep = A.L >= 64 ? 64 : 1;
             const size_t srow = (size_t)b * A.SC8 + A.sc8off + c8;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
@@ -405,7 +428,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = c8 * 8 + e;
-                    const float v = c < C ? wunet_lrelu(A.a0[c] * A.z0[((size_t)b * A.C0 + c) * (size_t)(2 * A.L) + q] + A.s0[c]) : 0.0f;
+                    const float v = c < C ? wunet_lrelu(av[e] * zq[k][e] + sv[e]) : 0.0f;
                     wunet_half a, d;
                     wunet_split_rt(A.bf, ss_ * v, a, d);
                     wunet_put_half(h, e, a);
