@@ -153,6 +153,26 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArg
 // Split-K forward conv: sum the z-slices' partial outputs, add the bias, write z, and reduce the BatchNorm
 // statistics.  grid = (C, rsplit): with rsplit == 1 (short levels) BatchNorm is finished in the same launch,
 // otherwise each block writes one partial row [blockIdx.y][C][2] for bn_finalize_fwd_kernel.
+// Sum of ksplit split-K partials (16 bytes each, `stride` floats apart) in split order, four loads in flight: written as a plain
+// loop over a run-time ksplit every load was followed by s_waitcnt vmcnt(0) - ksplit serialised memory round trips per thread.
+__device__ __forceinline__ wunet_f4 wunet_sum_splits4(const float* p, int ksplit, size_t stride)
+{
+    wunet_f4 v = wunet_f4{0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= ksplit; k += 4) {
+        const wunet_f4 t0 = wunet_ld4(p + (size_t)k * stride), t1 = wunet_ld4(p + (size_t)(k + 1) * stride);
+        const wunet_f4 t2 = wunet_ld4(p + (size_t)(k + 2) * stride), t3 = wunet_ld4(p + (size_t)(k + 3) * stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] += t0[j]; v[j] += t1[j]; v[j] += t2[j]; v[j] += t3[j]; }
+    }
+    for (; k < ksplit; ++k) {
+        const wunet_f4 t = wunet_ld4(p + (size_t)k * stride);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] += t[j];
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
                                                                         size_t split_stride, float* z, int B, int L, int logL,
                                                                         float* stats_rows)
@@ -171,12 +191,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
             const int p = p4 << 2;
             const int b = p >> logL, l = p & (L - 1);
             const size_t off = ((size_t)b * A.C + c) * L + l;
-            wunet_f4 v = wunet_f4{0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < ksplit; ++k) {
-                const wunet_f4 t = wunet_ld4(part + (size_t)k * split_stride + off);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += t[j];
-            }
+            const wunet_f4 v = wunet_sum_splits4(part + off, ksplit, split_stride);
             wunet_f4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -218,12 +233,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* p
         const size_t n4 = n >> 2;
         for (size_t i4 = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i4 < n4; i4 += (size_t)gridDim.x * WUNET_THREADS) {
             const size_t i = i4 << 2;
-            wunet_f4 v = wunet_f4{0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < ksplit; ++k) {
-                const wunet_f4 t = wunet_ld4(part + (size_t)k * n + i);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] += t[j];
-            }
+            wunet_f4 v = wunet_sum_splits4(part + i, ksplit, n);
             const float bv = bias ? bias[(i >> logL) % (size_t)C] : 0.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] += bv;
