@@ -32,8 +32,27 @@ def _conv_bn_act(x, sd, prefix, taps, training):
     return F.leaky_relu(y, SLOPE)
 
 
+def upsample_fp32_coords(h):
+    """x2 linear upsample, align_corners=True, of a float64 tensor with the source indices and weights ATen computes in FLOAT32
+    (UpSample.h area_pixel_compute_scale / _source_index, guard_index_and_lambda; model/unet_basic.py:93): the float64 arbiter of
+    the parity tests must interpolate at the reference's coordinates, otherwise it is itself 3.8e-4 away from the reference
+    (SURVEY.md section 7)."""
+    import numpy as np
+    lin = h.shape[-1]
+    lout = 2 * lin
+    scale = np.float32(lin - 1) / np.float32(lout - 1) if lout > 1 else np.float32(0)
+    src = (scale * np.arange(lout, dtype=np.float32)).astype(np.float32)
+    i0 = np.minimum(np.floor(src).astype(np.int64), lin - 1)
+    lam = np.clip((src - i0.astype(np.float32)).astype(np.float32), np.float32(0), np.float32(1))
+    i1 = i0 + (i0 < lin - 1)
+    l1 = torch.from_numpy(lam.astype(np.float64))
+    l0 = torch.from_numpy((np.float32(1) - lam).astype(np.float64))
+    return h[..., torch.from_numpy(i0)] * l0 + h[..., torch.from_numpy(i1)] * l1
+
+
 def forward(sd, noisy, n_layers=12, ci=24, training=True):
-    """sd: dict name -> torch tensor (running stats are updated in place when training)."""
+    """sd: dict name -> torch tensor (running stats are updated in place when training).  float64 tensors: the arbiter run
+    (same ops in double precision, the upsample at ATen's float32 coordinates)."""
     layers = conv_layers(n_layers, ci)
     enc, mid, dec = layers[:n_layers], layers[n_layers], layers[n_layers + 1:]
     skips = []
@@ -44,7 +63,7 @@ def forward(sd, noisy, n_layers=12, ci=24, training=True):
         h = h[:, :, ::2]
     h = _conv_bn_act(h, sd, mid[0], mid[3], training)   # :88
     for j, (prefix, _, _, k) in enumerate(dec):         # :91-96
-        h = F.interpolate(h, scale_factor=2, mode="linear", align_corners=True)
+        h = upsample_fp32_coords(h) if h.dtype == torch.float64 else F.interpolate(h, scale_factor=2, mode="linear", align_corners=True)
         h = torch.cat([h, skips[n_layers - 1 - j]], dim=1)
         h = _conv_bn_act(h, sd, prefix, k, training)
     h = torch.cat([h, noisy], dim=1)                    # :98

@@ -395,24 +395,30 @@ def test_gemm_paths_match_reference(pkg, dev, mode, n, ci, B, T):
     l2.backward()
     assert (out.detach().cpu() - o2.detach()).abs().max().item() < TOL
     assert abs(lv.item() - l2.item()) < 1e-5
+    # the arbiter: the same network in float64 (upsample at ATen's float32 coordinates).  Through 25 BatchNorm-backward passes the
+    # reference's OWN fp32 CPU arithmetic sits up to 6e-3 (tensor-relative) from it at batch 16, differently on every host
+    # (threading), so the HIP gradients are judged by their distance to the arbiter: at most twice the reference's distance
+    # (+1e-3), and inside the 1e-4 absolute bar.  Measured (tools/diag_gemm_ref.py): reference 5.9e-3, fp32 kernels 2.2e-3,
+    # split kernels 5.3e-3 on the worst tensor.
+    t64 = torch_port.state_to_torch(plan.golden_state(n, ci, 0), dtype=torch.float64, requires_grad=True)
+    o64 = torch_port.forward(t64, torch.from_numpy(noisy).double(), n, ci, True)
+    torch_port.loss_value("smooth_l1", torch.from_numpy(clean).double(), o64).backward()
     worst = 0.0
+    small = B * T < 16 * 16384
     for k, p in m.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("out"):
             continue
-        ref = tsd[k].grad
-        err = (p.grad.cpu() - ref).abs().max().item()
-        rel = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
+        ref, arb, got = tsd[k].grad.double(), t64[k].grad, p.grad.cpu().double()
+        err = (got - arb).abs().max().item()
+        rel = ((got - arb).norm() / (arb.norm() + 1e-30)).item()
+        rel_ref = ((ref - arb).norm() / (arb.norm() + 1e-30)).item()
         worst = max(worst, err)
         # LeakyReLU' is discontinuous: an activation within rounding distance of 0 (the split path's forward noise is ~1e-6,
         # fp32's ~2e-7) flips its slope between two equally valid roundings, and on a small net (a few hundred positions
         # behind a BatchNorm) one flip moves a whole gradient tensor by a few percent of its largest entry.  The 12-level
         # nets average thousands of them out and keep the flat 1e-4 bar.
-        small = B * T < 16 * 16384
-        bar = max(TOL, 5e-2 * ref.abs().max().item()) if small else TOL
-        # (non-small: 5e-3 - both arithmetics sit at 1.9e-3 on encoder.2's weight gradient, |g| ~ 5e-6: that is the fp32
-        # noise of the ATen CPU reference itself at batch 16; test_full_size_properties bounds the split path by the fp32 path)
-        # (1e-2: 5.8e-3 seen on encoder.4's weight gradient in the exact-fp32 mode on one box - the reference's CPU threading differs by host)
-        assert err < bar and rel < (6e-2 if small else 1e-2), (k, err, rel)
+        bar = max(TOL, 5e-2 * arb.abs().max().item()) if small else TOL
+        assert err < bar and rel < (6e-2 if small else 2.0 * rel_ref + 1e-3), (k, err, rel, rel_ref)
     print(f"gemm path mode={mode} n={n} B={B} T={T}: out err {(out.detach().cpu() - o2.detach()).abs().max().item():.2e}, worst grad err {worst:.2e}")
 
 
