@@ -144,7 +144,10 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
                                            ("WUNET_H3_XDMA=0 WUNET_H3_GRID=16 WUNET_H3_NOSPLIT=1", 2, (1, 20, 3, 2048)),
                                            # ... tiles of 2 .. 8 whole items (128 .. 32 samples), odd batch: items beyond the batch in the last tile
                                            ("WUNET_H3_XDMA=0 WUNET_H3_GRID=8", 2, (6, 16, 5, 1024)),
-                                           ("WUNET_H3_XDMA=0 WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1", 2, (5, 12, 3, 1024))])
+                                           ("WUNET_H3_XDMA=0 WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1", 2, (5, 12, 3, 1024)),
+                                           # conv_h3d_kernel with the DMA pieces issued between the MFMA passes (one basic block per stage)
+                                           ("WUNET_H3_IL=1 WUNET_H3_GRID=8", 2, (2, 24, 2, 1024)),
+                                           ("WUNET_H3_IL=1 WUNET_H3_GRID=16 WUNET_H3_NOSPLIT=1 WUNET_H3_ORDER=432 WUNET_H3D_ORDER=432", 2, (2, 40, 3, 1024))])
 def test_measurement_switches_are_bit_identical(switch, h3, cfg, monkeypatch):
     """The fused / re-mapped kernels of the default path compute exactly what the forms they replaced compute:
     one training step with and without the A/B switch gives the same output and the same gradients, bit for bit.

@@ -635,7 +635,8 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
         if (gx < 8) gx = 8;
         if (gx > nitems) gx = nitems;
         const dim3 grid((unsigned)gx, (unsigned)ksplit);
-        rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0);
+        const char* ile = getenv("WUNET_H3_IL");         // A/B switch: DMA pieces interleaved with the MFMA passes (un-segmented tiles)
+        rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, ile && atoi(ile) != 0 && !g_h3_trace);
     } else if (paired) {
         snprintf(pname, sizeof pname, "conv_h3p_kernel<%d, %d>", taps, mrep);
         prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));

@@ -131,10 +131,26 @@ __device__ __forceinline__ void wunet_dma16a(const void* g, wunet_lds_t lds_wave
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
+// ... skipped when the wave-uniform pred is 0, by a branch INSIDE the asm statement: the caller's code stays one basic block, so
+// hipcc can schedule the address arithmetic of the pieces between the MFMAs around them
+__device__ __forceinline__ void wunet_dma16a_if(int pred, const void* g, wunet_lds_t lds_wave_base)
+{
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    pred = __builtin_amdgcn_readfirstlane(pred);      // (an "s" operand the compiler holds in a VGPR is NOT moved to an SGPR for us)
+    unsigned keep;
+    asm volatile("s_cmp_lg_u32 %3, 0\n\ts_cbranch_scc0 .Lwunet_skip%=\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0\n.Lwunet_skip%=:"
+                 : "=&s"(keep) : "v"(g), "s"(lds), "s"(pred) : "memory", "scc");
+}
 // every DMA piece this wave issued has landed, then the workgroup barrier: all pieces of all waves are visible in LDS
 __device__ __forceinline__ void wunet_wait_dma_barrier() { asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory"); }
 // every LDS read / write this wave issued has completed, then the barrier (no vmcnt wait: DMAs stay in flight across it)
 __device__ __forceinline__ void wunet_wait_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wunet_wait_lds_barrier_if(int pred)       // (pred wave- and block-uniform; no basic-block split)
+{
+    pred = __builtin_amdgcn_readfirstlane(pred);
+    asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc0 .Lwunet_nobar%=\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n.Lwunet_nobar%=:" :: "s"(pred) : "memory", "scc");
+}
 __device__ __forceinline__ unsigned long long wunet_memtime() { return __builtin_amdgcn_s_memtime(); }
 // nothing is scheduled across this point (hipcc otherwise sinks LDS prefetches to their first use)
 #define wunet_sched_fence() __builtin_amdgcn_sched_barrier(0)
