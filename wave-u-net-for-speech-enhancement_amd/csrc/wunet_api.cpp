@@ -672,7 +672,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     if (dma && nseg == 1 && (tp == 128 || tp == 64) && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
         WgradH3dArgs a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
-        a.zero = reinterpret_cast<const wunet_half*>(zero);
+        (void)zero;
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
         snprintf(pname, sizeof pname, bf ? "wgrad_h3d_kernel<%d, %d, bf16>" : (tp == 64 ? "wgrad_h3d_kernel<%d, %d, 64>" : "wgrad_h3d_kernel<%d, %d>"), l.taps, l.h3w_mrep);
@@ -1069,7 +1069,6 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
     hipStream_t sd = (g_prof_on || no_side) ? st : side->stream;  // the per-kernel profiler serialises everything on one stream
 
     if (layer_end == NL) {
-        if (c->h3) hipMemsetAsync(ws + c->h3_slot, 0, 8 * sizeof(float), st);     // 32 zero bytes: the zero page of the DMA-staged weight gradient
         // flipped/transposed weights for every data gradient (one launch)
         PackTable tab{};
         int nd = 0;

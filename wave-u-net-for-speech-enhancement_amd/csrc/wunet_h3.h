@@ -13,6 +13,14 @@
 #pragma once
 #include "wunet_dev.h"
 
+// 16-byte zero page the LDS-DMA pieces that lie outside a tensor are fetched from (halo beyond an item, channel groups beyond C8):
+// one copy per translation unit, in the code object - nothing to allocate or clear per step
+#ifdef WUNET_EMU
+static const unsigned wunet_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+static __device__ __attribute__((aligned(16))) const unsigned wunet_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
 // ---------------------------------------------------------------------------- conv / data gradient
 // Implicit GEMM like conv_mfma_kernel, 256 positions x M_REP*16 rows per block, K walked as chunks of 32 channels x
 // groups of TG=5 taps.  NSEG = 1: L >= 256, the tile lies inside one batch item; NSEG = 2 .. 16: L = 128 .. 16, the tile is
@@ -691,7 +699,6 @@ __global__ __launch_bounds__(WUNET_THREADS, (M_REP <= 2 ? 2 : 1)) void wgrad_h3_
 struct WgradH3dArgs {
     const wunet_half* xh; const wunet_half* xl;
     const wunet_half* gh; const wunet_half* gl;
-    const wunet_half* zero;   // >= 16 zero bytes in global memory
     const float* sc;          // {scale, 1/scale} of g_z
     const float* sc2;         // {scale, 1/scale} of x
     float* part;
@@ -754,6 +761,7 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
         xrow[it] = r - 8;
         xsrc[it] = ((long long)c8 * L + (r - 8)) * 8;
     }
+    const wunet_half* const zero_ = reinterpret_cast<const wunet_half*>(wunet_zero16);
     // issue the DMA of chunk K_ into buffer BUF_
 #define WUNET_WH3D_DMA(K_, BUF_)                                                                                  \
     {                                                                                                             \
@@ -763,7 +771,7 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
         _Pragma("unroll") for (int it = 0; it < GIT; ++it) {                                                      \
             if (gsel[it] >= 0) {                                                                                  \
                 const wunet_half* src_ = (gsel[it] & 2) ? A.gl : A.gh;                                            \
-                const wunet_half* p_ = (gsel[it] & 1) ? src_ + (size_t)b_ * A.GC8 * L * 8 + gsrc[it] + (size_t)l0_ * 8 : A.zero; \
+                const wunet_half* p_ = (gsel[it] & 1) ? src_ + (size_t)b_ * A.GC8 * L * 8 + gsrc[it] + (size_t)l0_ * 8 : zero_; \
                 wunet_dma16(p_, dst_ + (size_t)it * WUNET_THREADS * 8);                                           \
             }                                                                                                     \
         }                                                                                                         \
@@ -772,7 +780,7 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
                 const int l_ = l0_ + xrow[it];                                                                    \
                 const wunet_half* src_ = (xsel[it] & 2) ? A.xl : A.xh;                                            \
                 const wunet_half* p_ = ((xsel[it] & 1) && l_ >= 0 && l_ < L)                                      \
-                                           ? src_ + (size_t)b_ * A.XC8 * L * 8 + xsrc[it] + (size_t)l0_ * 8 : A.zero; \
+                                           ? src_ + (size_t)b_ * A.XC8 * L * 8 + xsrc[it] + (size_t)l0_ * 8 : zero_; \
                 wunet_dma16(p_, dst_ + (size_t)GPCS * 8 + (size_t)it * WUNET_THREADS * 8);                        \
             }                                                                                                     \
         }                                                                                                         \

@@ -17,11 +17,6 @@
 #pragma once
 #include "wunet_h3.h"
 
-#ifdef WUNET_EMU
-static const unsigned wunet_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#else
-static __device__ __attribute__((aligned(16))) const unsigned wunet_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
 
 // IL: the DMA pieces of the next stage are issued BETWEEN the MFMA passes of the current one, predicated inside their asm statements
 // (no branch in the stage body: one basic block, so the address arithmetic of a piece is scheduled into the issue slots the
