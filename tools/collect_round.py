@@ -17,9 +17,29 @@ for src, dst in (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_b
 raw = json.load(open(os.path.join(F, "pmc_raw.json")))
 # the PMC runs execute 3 steps (1 warm-up + 2): launches / 3 = launches per step.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE
 # under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section): doubled.
-kern, whole = {}, 0.0
+def lib_name(k):
+    """rocprofv3's kernel name -> the name the library's HIP-event profiler (and bench.py's roofline) uses for the same kernel:
+    the split kernels drop their boolean / chunk template arguments (bf16 and the 64-position chunk are spelled out)."""
+    if "<" not in k:
+        return k
+    base, args = k.split("<", 1)
+    a = [t.strip() for t in args.rstrip(">").split(",")]
+    if base in ("conv_h3d_kernel", "conv_h3_kernel"):
+        return "%s<%s, %s, %s%s>" % (base, a[0], a[1], a[2], ", bf16" if len(a) > 3 and a[3] == "true" else "")
+    if base == "wgrad_h3d_kernel":
+        return "%s<%s, %s%s>" % (base, a[0], a[1], ", bf16" if a[3] == "true" else (", 64" if len(a) > 4 and a[4] == "64" else ""))
+    if base == "wgrad_h3_kernel":
+        return "%s<%s, %s%s>" % (base, a[0], a[1], ", bf16" if len(a) > 4 and a[4] == "true" else "")
+    return k
+
+
+acc = {}
 for k, (n, fs) in raw["fetch"].items():
     wn, ws = raw["write"].get(k, [0, 0.0])
+    e = acc.setdefault(lib_name(k), [0, 0.0, 0, 0.0])
+    e[0] += n; e[1] += fs; e[2] += wn; e[3] += ws
+kern, whole = {}, 0.0
+for k, (n, fs, wn, ws) in acc.items():
     per = (2.0 * fs / n + (ws / wn if wn else 0.0)) * 1024.0
     kern[k] = {"launches_per_step": n / 3.0, "FETCH_SIZE_KiB": round(fs / n, 1), "WRITE_SIZE_KiB": round(ws / wn if wn else 0.0, 1),
                "hbm_bytes_per_launch": int(per)}
