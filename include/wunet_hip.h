@@ -39,7 +39,10 @@ typedef struct wunet_ctx wunet_ctx;
 const char* wunet_last_error(void);
 
 /* Replaces Model.__init__ shape bookkeeping (model/unet_basic.py:33-75) for one (batch, length).
- * length must be a power of two >= 4 with length >> n_layers >= 1 (levels of 1-2 samples take a scalar path).
+ * length >= 4 and divisible by 2^n_layers, as model/unet_basic.py:86,93 requires (levels of 1-2 samples take a scalar path).  The
+ * kernels index rows with shifts and masks: a length that is not a power of two (m * 2^k) is carried in rows padded to the next
+ * power of two inside the workspace (zeros where a conv reads the padding, none of it in the BatchNorm statistics, no gradient
+ * for it, the upsample at the coordinates of the lengths that exist); the caller's tensors keep their own [B][1][length] layout.
  * Host-side object, no device memory. */
 int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out);
 void wunet_destroy(wunet_ctx* ctx);

@@ -247,6 +247,11 @@ inline hipError_t hipFree(void* p) { std::free(p); return 0; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { std::memcpy(d, s, n); return 0; }
 #define hipMemcpyDeviceToDevice 3
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, int, hipStream_t)
+{
+    for (size_t r = 0; r < height; ++r) std::memcpy(static_cast<char*>(d) + r * dpitch, static_cast<const char*>(s) + r * spitch, width);
+    return 0;
+}
 inline hipError_t hipGetLastError() { return 0; }
 #define hipStreamNonBlocking 1
 #define hipEventDisableTiming 2

@@ -34,8 +34,10 @@ def test_shape_errors_come_back_as_codes_not_crashes():
     lib_mod = importlib.import_module(PKG_NAME + "._lib")
     lib = lib_mod.declare(ctypes.CDLL(lib_mod.LIB_PATH))
     h = ctypes.c_void_p()
-    assert lib.wunet_create(12, 24, 4, 16000, ctypes.byref(h)) == -1          # not a power of two (reference: 16000 fails too)
-    assert b"power of two" in lib.wunet_last_error()
+    assert lib.wunet_create(12, 24, 4, 16000, ctypes.byref(h)) == -1          # not divisible by 2^12 (reference: 16000 fails too, unet_basic.py:86,93)
+    assert b"divisible by 2^n_layers" in lib.wunet_last_error()
+    assert lib.wunet_create(12, 24, 4, 12288, ctypes.byref(h)) == 0           # 3 * 2^12: rows padded to 16384 inside
+    lib.wunet_destroy(h)
     assert lib.wunet_create(12, 24, 4, 2048, ctypes.byref(h)) == -1           # 2048 >> 12 = 0: deeper than log2(T)
     assert lib.wunet_create(0, 24, 4, 16384, ctypes.byref(h)) == -1
     assert lib.wunet_create(12, 24, 4, 16384, ctypes.byref(h)) == 0

@@ -33,7 +33,9 @@ def _build(n, ci, emu_engine):
 
 @pytest.mark.parametrize("n,ci,B,T,loss", [(2, 4, 2, 32, "mse"), (3, 8, 3, 64, "l1"), (2, 24, 1, 1024, "smooth_l1"),
                                             (1, 5, 1, 8, "mse"), (3, 10, 3, 128, "smooth_l1"),
-                                            (4, 4, 2, 16, "mse"), (5, 6, 3, 64, "l1"), (3, 8, 2, 16, "smooth_l1")])   # middle of 1 / 2 samples
+                                            (4, 4, 2, 16, "mse"), (5, 6, 3, 64, "l1"), (3, 8, 2, 16, "smooth_l1"),    # middle of 1 / 2 samples
+                                            # lengths m * 2^n (model/unet_basic.py:86,93 accepts them): rows padded to the next power of two
+                                            (3, 8, 2, 96, "mse"), (2, 4, 3, 24, "l1"), (4, 6, 2, 80, "smooth_l1"), (2, 12, 1, 1536, "mse")])
 def test_train_step_matches_oracle(emu_engine, n, ci, B, T, loss):
     m, sd, pkg_loss = _build(n, ci, emu_engine)
     noisy, clean = plan.golden_batch(B, T, 0)
@@ -71,7 +73,9 @@ def emu_engine_h3():
                                             (3, 16, 3, 1024, "mse"),           # 128-sample level: two-item tiles (odd batch: a half-empty tile), split-K
                                             (1, 20, 3, 512, "l1"),             # channel counts that are not multiples of 8
                                             (4, 16, 5, 1024, "smooth_l1"),     # 64-sample level: four-item conv tiles, two-item wgrad chunks, odd batch
-                                            (6, 16, 17, 1024, "mse")])         # 32- and 16-sample levels: 2 / 4 items under one wave
+                                            (6, 16, 17, 1024, "mse"),          # 32- and 16-sample levels: 2 / 4 items under one wave
+                                            (2, 24, 2, 1536, "smooth_l1"),     # 3 * 512 samples: levels of 1536 / 768 / 384 in rows of 2048 / 1024 / 512
+                                            (3, 16, 3, 768, "mse")])           # ... 768 / 384 / 192 / 96: segmented tiles with padded items
 def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
     """Same comparison as test_train_step_matches_oracle with the fp16-split path forced on: output within 2e-5, every
     gradient within 3e-4 of its tensor's largest entry (the f32-vs-f64 noise floor of these nets is 1.5e-4).  The
@@ -199,8 +203,9 @@ def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3):
         assert torch.equal(a, b), k
 
 
-def test_eval_forward_matches_oracle(emu_engine):
-    n, ci, B, T = 3, 4, 2, 64
+@pytest.mark.parametrize("T", [64, 96])          # 96 = 3 * 2^5: rows padded to 128 inside
+def test_eval_forward_matches_oracle(emu_engine, T):
+    n, ci, B = 3, 4, 2
     m, sd, _ = _build(n, ci, emu_engine)
     noisy, _ = plan.golden_batch(B, T, 0)
     ref = c_oracle.step(sd, noisy, None, n, ci, False, want_grads=False, precision="f64")

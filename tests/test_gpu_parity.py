@@ -336,7 +336,10 @@ def test_chunked_inference_vs_reference_loop(pkg, dev):
 @pytest.mark.parametrize("n,ci,B,T,loss", [(1, 24, 1, 64, "mse"), (3, 10, 3, 512, "smooth_l1"), (5, 7, 5, 2048, "l1"),
                                             (12, 24, 1, 16384, "mse"), (10, 24, 2, 65536, "mse"),
                                             (14, 24, 2, 16384, "mse"),     # deepest net 16384 samples allow: middle of ONE sample
-                                            (16, 24, 2, 65536, "mse")])    # BASELINE configs[4] geometry (16 levels), fp32
+                                            (16, 24, 2, 65536, "mse"),     # BASELINE configs[4] geometry (16 levels), fp32
+                                            # lengths m * 2^n (model/unet_basic.py:86,93): rows padded to the next power of two inside
+                                            (3, 10, 3, 96, "l1"), (4, 6, 2, 80, "smooth_l1"), (5, 24, 2, 3072, "mse"),
+                                            (12, 24, 2, 12288, "mse")])    # 3 * 2^12: the 12-level net on 12288-sample frames
 def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
     """Ragged / extreme shapes of the reference's domain: one level, batch 1 (BatchNorm over a single item),
     channel intervals that are not multiples of 4/8/16/24, odd batches, 65536-sample frames."""
@@ -361,7 +364,8 @@ def test_odd_shapes_vs_oracle(pkg, dev, n, ci, B, T, loss):
 @pytest.mark.parametrize("mode,n,ci,B,T", [(1, 12, 24, 16, 16384),     # default planner: the levels >= 256 samples on the fp16-split kernels
                                             (0, 12, 24, 16, 16384),     # WUNET_H3=0: the same net on the fp32 MFMA kernels only
                                             (2, 3, 20, 3, 2048),        # forced split path on a small odd shape (ragged channel groups)
-                                            (2, 2, 24, 2, 1024)])
+                                            (2, 2, 24, 2, 1024),
+                                            (2, 3, 16, 3, 768)])        # ... on 768 = 3 * 2^8 samples (rows of 1024 / 512 / 256 / 128)
 def test_gemm_paths_match_reference(pkg, dev, mode, n, ci, B, T):
     """Both GEMM arithmetics against the reference's ATen CPU path at the same 1e-4 bar: the fp16-split kernels
     (3 passes of v_mfma_f32_16x16x32_f16 on hi/lo halves, power-of-two scaled gradients, conv_h3 / wgrad_h3 / prep_h3 /

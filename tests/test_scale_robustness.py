@@ -155,3 +155,25 @@ def test_split_path_on_a_trained_like_state():
     oe0, ge0 = errors(out0, g0, ref)
     assert oe3 <= 1e-5 and ge3 <= 1e-4, (oe3, ge3, oe0, ge0)
     assert oe3 <= 3 * oe0 + 2e-6 and ge3 <= 3 * ge0 + 2e-6, (oe3, ge3, oe0, ge0)
+
+
+def test_split_path_on_a_length_that_is_not_a_power_of_two():
+    """model/unet_basic.py:86,93 accepts any length divisible by 2^n_layers.  768 = 3 * 2^8 samples (levels of 768 / 384 / 192 / 96 in
+    rows of 1024 / 512 / 256 / 128): training step and eval forward of the split path and of the fp32 path against the f64 oracle,
+    including the bucketed backward GradSync drives."""
+    n, ci, B, T = 3, 16, 2, 768
+    sd = rescaled_state(n, ci)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, True, "mse", precision="f64")
+    for h3 in (2, 0):
+        out, grads = run_step(_engine(h3), sd, n, ci, noisy, clean, train=True)
+        assert out.shape == (B, 1, T)
+        assert np.abs(out - ref["out"]).max() < 1e-5
+        for k, g in grads.items():
+            if k.endswith(".0.bias") and not k.startswith("out"):
+                continue
+            r = ref["grads"][k]
+            assert np.linalg.norm((g - r).ravel()) <= 1e-4 * np.linalg.norm(r.ravel()) + 1e-9, (h3, k)
+    refe = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, False, "mse", precision="f64")
+    oute, _ = run_step(_engine(2), sd, n, ci, noisy, clean, train=False)
+    assert np.abs(oute - refe["out"]).max() < 1e-5

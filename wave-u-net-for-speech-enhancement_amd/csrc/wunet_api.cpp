@@ -261,6 +261,7 @@ enum { LK_RAW = 0, LK_DECIM = 1, LK_UPCAT = 2 };
 
 struct LayerPlan {
     int cin, cout, taps, L, logL, kind;
+    int Lt;              // samples of a row that exist: L is the power-of-two row stride, Lt <= L (lengths m*2^n; Lt == L otherwise)
     int src0, src1;      // producer layers (src0 = -1: network input)
     int c0;              // UPCAT: channels from the upsampled branch
     ConvCfg f;           // forward conv (rows = cout, K channels = cin)
@@ -289,6 +290,9 @@ struct LayerPlan {
 
 struct wunet_ctx {
     int n, ci, B, T, NL;
+    int Tt = 0;                   // the caller's frame length (T: rounded up to a power of two, the row stride of every level)
+    bool padded = false;          // Tt < T
+    size_t pad_in = 0, pad_out = 0, pad_gout = 0;      // padded copies of noisy / enhanced / grad_enhanced (float offsets; padded only)
     std::vector<LayerPlan> ly;
     size_t stats_off, wpkf_off, spart_off, fwd_floats;
     size_t bmax_off, bound_off;   // pass A maxima / per-channel |g_z| bounds (fp16-split scale)
@@ -451,8 +455,10 @@ void layout_workspace(wunet_ctx* c)
         l.f_wpk = wpk;
         wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
         if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
-        if (l.f.ksplit > 1 && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
-        if (l.f.ksplit > 1 && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
+        // (a padded length takes every conv but the first through the bias-free buffer and conv_reduce_bn_kernel: its statistics skip
+        // the row padding, the conv kernels need not know)
+        if ((l.f.ksplit > 1 || c->padded) && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
+        if ((l.f.ksplit > 1 || c->padded) && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
         if (l.L < 4 && (size_t)B * l.cout * l.L > spart_max) spart_max = (size_t)B * l.cout * l.L;
         if (i > 0 && l.d.ksplit > 1 && (size_t)l.d.ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d.ksplit * B * l.cin * l.L;
         l.z = off; off += align64((size_t)B * l.cout * l.L);
@@ -498,6 +504,10 @@ void layout_workspace(wunet_ctx* c)
         if (!l.h3f) continue;
         c->ly[l.src0].feeds_h3 = 1;
         if (l.kind == LK_UPCAT) c->ly[l.src1].feeds_h3 = 1;
+    }
+    if (c->padded) {            // padded copies of the caller's tensors (rows of T floats, the caller's hold Tt)
+        c->pad_in = off; off += align64((size_t)B * T);
+        c->pad_out = off; off += align64((size_t)B * T);
     }
     c->fwd_floats = off;
 
@@ -545,6 +555,7 @@ void layout_workspace(wunet_ctx* c)
     c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
     (void)gzs;
     c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // 8 zero floats (DMA zero page), then {scale, 1/scale} of g_z per layer (offset 8 + 4*layer)
+    if (c->padded) { c->pad_gout = off; off += align64((size_t)B * T); }
     c->total_floats = off;
 }
 
@@ -731,13 +742,19 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
     if (!out) return fail(WUNET_E_ARG, "out is null");
     if (n_layers < 1 || 2 * n_layers + 1 > WUNET_MAX_CONV_LAYERS) return fail(WUNET_E_ARG, "n_layers=%d unsupported (1..16)", n_layers);
     if (channels_interval < 1 || batch < 1) return fail(WUNET_E_ARG, "bad channels_interval/batch");
-    if (!is_pow2(length) || (length >> n_layers) < 1 || length < 4)
-        return fail(WUNET_E_ARG, "length=%d unsupported: must be a power of two >= 4 with length >> n_layers >= 1", length);
-    const int n = n_layers, ci = channels_interval, B = batch, T = length;
+    // model/unet_basic.py:86,93 accepts any length divisible by 2^n_layers.  A length m*2^k (m odd > 1) is carried in rows padded to
+    // the next power of two: the padding holds zeros wherever a conv reads it (== the conv's own zero padding), is left out of the
+    // BatchNorm statistics and gets no gradient; the upsample uses the coordinates of the lengths that exist.
+    if (length < 4 || (length % (1 << n_layers)) != 0 || (length >> n_layers) < 1)
+        return fail(WUNET_E_ARG, "length=%d unsupported: must be >= 4 and divisible by 2^n_layers (n_layers=%d)", length, n_layers);
+    int Tp = 4;
+    while (Tp < length) Tp <<= 1;
+    const int n = n_layers, ci = channels_interval, B = batch, T = Tp;
     if ((long long)B * (2 * n + 1) * ci * T >= (1LL << 32)) return fail(WUNET_E_ARG, "tensor too large for 32-bit offsets");
 
     wunet_ctx* c = new wunet_ctx();
     c->n = n; c->ci = ci; c->B = B; c->T = T; c->NL = 2 * n + 1;
+    c->Tt = length; c->padded = length != T;
     c->ly.resize(c->NL);
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
@@ -754,6 +771,7 @@ int wunet_create(int n_layers, int channels_interval, int batch, int length, wun
             l.cin = l.c0 + c->ly[l.src1].cout;
         }
         l.logL = ilog2(l.L);
+        l.Lt = (int)(((long long)l.L * length) / T);       // (T / L is the level's decimation factor, a power of two dividing length)
     }
     layout_workspace(c);
     *out = c;
@@ -808,6 +826,16 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     // L2/HBM bandwidth and CU slots from the encoder GEMMs), so it stays on the caller's stream.
     hipStream_t sd = st;
     float* const fslot = ws + c->fslot_off;
+    float* const enhanced_user = enhanced;
+    if (c->padded) {
+        // the caller's [B][1][Tt] rows into zero-padded rows of T floats; the result is cropped back at the end
+        if (hipMemsetAsync(ws + c->pad_in, 0, (size_t)c->B * c->T * sizeof(float), st) != hipSuccess ||
+            hipMemcpy2DAsync(ws + c->pad_in, (size_t)c->T * sizeof(float), noisy, (size_t)c->Tt * sizeof(float), (size_t)c->Tt * sizeof(float),
+                             (size_t)c->B, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return fail(WUNET_E_RUNTIME, "padding the input failed");
+        noisy = ws + c->pad_in;
+        enhanced = ws + c->pad_out;
+    }
     // 1. pack all forward weights into MFMA-fragment order (one launch)
     {
         PackTable tab{};
@@ -835,7 +863,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 ScaleDesc& d = T.d[i];
                 d.w = (l.h3f || l.h3d) ? params[4 * i] : nullptr; d.wn = (unsigned)((size_t)l.cout * l.cin * l.taps);
                 d.gamma = params[4 * i + 2]; d.beta = params[4 * i + 3]; d.C = l.cout;
-                d.sqrtn = sqrtf((float)((double)c->B * l.L));
+                d.sqrtn = sqrtf((float)((double)c->B * l.Lt));
                 any = any || l.h3f;
             }
             T.wmax = ws + c->wmax_off; T.slots = ws + c->fslot_off; T.training = training ? 1 : 0;
@@ -870,7 +898,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             const LayerPlan& p = c->ly[l.src0];
             PrepArgs pa{};
             pa.z0 = ws + p.z; pa.a0 = ws + p.a; pa.s0 = ws + p.s; pa.x = ws + l.xin;
-            pa.B = c->B; pa.C0 = l.c0; pa.C1 = l.cin - l.c0; pa.L = l.L; pa.logL = l.logL;
+            pa.B = c->B; pa.C0 = l.c0; pa.C1 = l.cin - l.c0; pa.L = l.L; pa.logL = l.logL; pa.Lt = l.Lt;
             const size_t n4 = (size_t)c->B * l.cin * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;
             if (blocks > 8192) blocks = 8192;
@@ -878,7 +906,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 PrepH3Args ph{};
                 ph.z0 = pa.z0; ph.a0 = pa.a0; ph.s0 = pa.s0;
                 ph.xh = reinterpret_cast<wunet_half*>(ws + l.xh); ph.xl = reinterpret_cast<wunet_half*>(ws + l.xl);
-                ph.B = c->B; ph.C0 = l.c0; ph.C1 = l.cin - l.c0; ph.C8 = (l.cin + 7) / 8; ph.L = l.L; ph.logL = l.logL;
+                ph.B = c->B; ph.C0 = l.c0; ph.C1 = l.cin - l.c0; ph.C8 = (l.cin + 7) / 8; ph.L = l.L; ph.logL = l.logL; ph.Lt = l.Lt;
                 ph.kind = l.kind == LK_UPCAT ? 1 : 0;
                 // the encoder-side pass can only write the decoder's skip half when the decoder's x scale is known that early:
                 // training mode (data-independent activation bounds); in eval mode the decoder-side pass reads the skip itself
@@ -900,12 +928,12 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 if (l.kind == LK_UPCAT) {
                     const LayerPlan& k = c->ly[l.src1];
                     ph.z1 = ws + k.z; ph.a1 = ws + k.a; ph.s1 = ws + k.s;
-                    ph.up_scale = (float)(l.L / 2 - 1) / (float)(l.L - 1);
+                    ph.up_scale = (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1);
                 }
                 const size_t nt = (size_t)c->B * (ph.up_only ? ph.C0 / 8 : ph.C8) * (l.L / 4);
                 size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (hb > 16384) hb = 16384;
-                const bool prep4 = getenv("WUNET_PREP4") != nullptr;                      // A/B switch (read per launch: tests toggle it)
+                const bool prep4 = getenv("WUNET_PREP4") != nullptr && !c->padded;                      // A/B switch (read per launch: tests toggle it)
                 if (prep4) {
                     WUNET_LAUNCH(prep4_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, ph);
                 } else {
@@ -929,7 +957,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 if (l.kind == LK_UPCAT) {
                     const LayerPlan& k = c->ly[l.src1];
                     pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
-                    pa.up_scale = l.L > 1 ? (float)(l.L / 2 - 1) / (float)(l.L - 1) : 0.f;
+                    pa.up_scale = l.Lt > 1 ? (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1) : 0.f;
                 }
                 const size_t ne = (size_t)c->B * l.cin * l.L;
                 WUNET_LAUNCH(prep_scalar_kernel, dim3((unsigned)((ne + WUNET_THREADS - 1) / WUNET_THREADS)), dim3(WUNET_THREADS), 0, st, pa,
@@ -939,7 +967,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             } else {
                 const LayerPlan& k = c->ly[l.src1];
                 pa.z1 = ws + k.z; pa.a1 = ws + k.a; pa.s1 = ws + k.s;
-                pa.up_scale = l.L > 1 ? (float)(l.L / 2 - 1) / (float)(l.L - 1) : 0.f;
+                pa.up_scale = l.Lt > 1 ? (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1) : 0.f;
                 WUNET_LAUNCH(prep_upcat_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, pa, 0, l.cin);
             }
             WUNET_CHECK_LAUNCH();
@@ -947,14 +975,14 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         }
         // 2b. conv (+ bias, + per-wave BN statistics partials) on the matrix cores
         const bool tiny = l.L < 4;
-        const bool split = l.f.ksplit > 1 || tiny;      // both leave a bias-free result in the split buffer
+        const bool split = l.f.ksplit > 1 || tiny || (c->padded && !l.first);      // all leave a bias-free result in the split buffer
         // BatchNorm statistics -> scale/shift for the consumers (+ running stats); eval mode: from the running statistics
         BnFwdArgs b{};
         b.stats = ws + c->stats_off; b.rows = l.f_rows; b.bias = params[4 * i + 1];
         b.gamma = params[4 * i + 2]; b.beta = params[4 * i + 3];
         b.running_mean = running[2 * i]; b.running_var = running[2 * i + 1]; b.nbt = nbt[i];
         b.a = ws + l.a; b.s = ws + l.s; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
-        b.C = l.cout; b.count = (double)c->B * l.L; b.training = training ? 1 : 0;
+        b.C = l.cout; b.count = (double)c->B * l.Lt; b.training = training ? 1 : 0;
         // eval mode, a layer whose activation feeds split operands: its consumers' operand scale comes from the measured maximum
         // of |a z + s| (no batch statistics bound it).  The large producers (conv_first_kernel, un-split conv_h3_kernel) take it
         // in their epilogue - the BatchNorm coefficients only depend on the running statistics, so they are finalised BEFORE the
@@ -970,7 +998,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             prof_begin(st, "conv_first_kernel<15>", 2.0 * c->B * l.L * l.cout * 15.0, 4.0 * c->B * l.L * (1.0 + l.cout));
             WUNET_LAUNCH(conv_first_kernel<15>, dim3((unsigned)l.f.grid_x), dim3(WUNET_THREADS), 0, st, xin, params[4 * i], params[4 * i + 1],
                          ws + l.z, training ? ws + c->stats_off : (float*)nullptr, c->B, l.cout, l.L, l.logL,
-                         ev_epi ? ws + l.a : (const float*)nullptr, ev_epi ? ws + l.s : (const float*)nullptr, ev_epi ? xrows : (float*)nullptr);
+                         ev_epi ? ws + l.a : (const float*)nullptr, ev_epi ? ws + l.s : (const float*)nullptr, ev_epi ? xrows : (float*)nullptr, l.Lt);
             prof_end(st);
         } else if (l.h3f) {
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
@@ -1013,7 +1041,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             if (rs > 64) rs = 64;
             b.rows = rs;
             WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout, rs), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
-                         tiny ? 1 : l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off);
+                         tiny ? 1 : l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off, l.Lt);
             if (rs > 1) {
                 WUNET_CHECK_LAUNCH();
                 WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
@@ -1046,6 +1074,9 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         prof_end(st);
         WUNET_CHECK_LAUNCH();
     }
+    if (c->padded && hipMemcpy2DAsync(enhanced_user, (size_t)c->Tt * sizeof(float), ws + c->pad_out, (size_t)c->T * sizeof(float),
+                                      (size_t)c->Tt * sizeof(float), (size_t)c->B, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return fail(WUNET_E_RUNTIME, "cropping the output failed");
     return WUNET_OK;
 }
 
@@ -1067,6 +1098,16 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
     if (!side) return WUNET_E_RUNTIME;
     static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr;     // A/B switch for measurements
     hipStream_t sd = (g_prof_on || no_side) ? st : side->stream;  // the per-kernel profiler serialises everything on one stream
+    if (c->padded) {
+        // the forward's zero-padded copies of the input and of the result are still in the workspace; the incoming gradient is
+        // padded with zeros here (the head's backward then gives the row padding a zero gradient)
+        if (layer_end == NL &&
+            (hipMemsetAsync(ws + c->pad_gout, 0, (size_t)c->B * c->T * sizeof(float), st) != hipSuccess ||
+             hipMemcpy2DAsync(ws + c->pad_gout, (size_t)c->T * sizeof(float), grad_enhanced, (size_t)c->Tt * sizeof(float),
+                              (size_t)c->Tt * sizeof(float), (size_t)c->B, hipMemcpyDeviceToDevice, st) != hipSuccess))
+            return fail(WUNET_E_RUNTIME, "padding the output gradient failed");
+        noisy = ws + c->pad_in; enhanced = ws + c->pad_out; grad_enhanced = ws + c->pad_gout;
+    }
 
     if (layer_end == NL) {
         // flipped/transposed weights for every data gradient (one launch)
@@ -1121,7 +1162,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         // ---- pass A: assemble dL/d(BN output), LeakyReLU', BN-backward partial sums
         PassAArgs p{};
         p.z = ws + l.z; p.a = ws + l.a; p.s = ws + l.s; p.mean = ws + l.mean; p.rstd = ws + l.rstd;
-        p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL;
+        p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL; p.Lt = l.Lt;
         const dim3 ga(l.cout, l.a_split);
         const bool tiny = l.L < 4;
         // a whole channel in one pass of one block (the levels of <= 16 samples at batch 64): BatchNorm-backward finalize and
@@ -1130,7 +1171,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                           !getenv("WUNET_NO_PASSA_FUSE");
         if (fuse) {
             p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
-            p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.L;
+            p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.Lt;
         }
         {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
             const double pe = (double)c->B * l.cout * l.L;
@@ -1147,7 +1188,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         } else if (i >= n) {
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + nx.dx; p.Cg0 = nx.cin;
-            p.up_scale = (float)(l.L - 1) / (float)(2 * l.L - 1);
+            p.up_scale = (float)(l.Lt - 1) / (float)(2 * l.Lt - 1);
             p.no_fast = getenv("WUNET_NO_PASSA_FAST") ? 1 : 0;
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_UP>, ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_UP, true>), ga, dim3(WUNET_THREADS), 0, st, p);
@@ -1167,7 +1208,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             BnBwdArgs b{};
             b.part = ws + c->bpart_off; b.rows = l.a_split; b.gamma = params[4 * i + 2]; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
             b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
-            b.C = l.cout; b.count = (double)c->B * l.L;
+            b.C = l.cout; b.count = (double)c->B * l.Lt;
             b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
             WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
             WUNET_CHECK_LAUNCH();
@@ -1186,7 +1227,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                  (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
                                  ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                 c->B, l.cout, c8, l.L, l.logL, c->bf);
+                                 c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt);
                     prof_end(st);
                 } else if (tiny)
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
@@ -1194,7 +1235,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                  (size_t)c->B * l.cout * l.L, ws + l.g);
                 else
                     WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                                 (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g);   // in place
+                                 (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g, l.Lt);   // in place
                 WUNET_CHECK_LAUNCH();
             }
         }

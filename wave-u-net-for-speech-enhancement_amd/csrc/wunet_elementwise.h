@@ -175,7 +175,7 @@ __device__ __forceinline__ wunet_f4 wunet_sum_splits4(const float* p, int ksplit
 
 __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
                                                                         size_t split_stride, float* z, int B, int L, int logL,
-                                                                        float* stats_rows)
+                                                                        float* stats_rows, int Lt)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -196,8 +196,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 o[j] = v[j] + bias;
-                s1 += (double)v[j];
-                s2 += (double)v[j] * (double)v[j];
+                if (l + j < Lt) {                                 // (row padding does not count)
+                    s1 += (double)v[j];
+                    s2 += (double)v[j] * (double)v[j];
+                }
             }
             wunet_st4(z + off, o);
         }
@@ -210,8 +212,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
             float v = 0.0f;
             for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * split_stride + off];
             z[off] = v + bias;
-            s1 += (double)v;
-            s2 += (double)v * (double)v;
+            if (l < Lt) {
+                s1 += (double)v;
+                s2 += (double)v * (double)v;
+            }
         }
     }
     block_sum2(s1, s2, red);
@@ -341,8 +345,9 @@ struct PassAArgs {
     int Cg0;             // channel count of the g0 tensor
     int coff;            // ENC: channel offset of the skip part inside dXdec
     int B, C, L, logL;
-    float up_scale;      // UP: (float)(L-1)/(2L-1)
+    float up_scale;      // UP: (float)(Lt-1)/(2Lt-1)
     int no_fast;         // UP: A/B switch, generic upsample^T walk for every thread
+    int Lt;              // samples of a row that exist (<= L, the power-of-two row stride; PrepArgs::Lt): the padding gets no gradient
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
     const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     float mg = 0.0f, mz = 0.0f;
     wunet_f4 keep_g = wunet_f4{0.f, 0.f, 0.f, 0.f}, keep_z = keep_g;
     size_t keep_i = 0;
+    int keep_l = 0;
     bool have = false;
     for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += WUNET_THREADS) {
         const size_t p = q4 << 2;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             // transpose of ATen's upsample_linear1d: output j contributes l0 to input i0(j) and l1 to i1(j), with the
             // fp32-computed coordinates; inputs l..l+3 can only be hit by outputs j in [2l-2, 2l+8], walked in
             // ascending j like ATen's backward loop
-            const int Lo = 2 * A.L;
+            const int Lo = 2 * A.L, Lot = 2 * A.Lt;               // row stride / samples that exist of the upsampled tensor
             const float* row = A.g0 + ((size_t)b * A.Cg0 + c) * Lo;
             float d[12];
             const int j0 = 2 * l - 4;                         // 16-byte aligned
@@ -401,13 +407,13 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             // interior threads: ATen's source pair of output j is ((j-1)>>1, +1) (checked against the exact coordinates), so
             // input i receives, in ascending j, l1(2i-1) d[2i-1] + l1(2i) d[2i] + l0(2i+1) d[2i+1] + l0(2i+2) d[2i+2]: four
             // multiply-adds instead of eleven rounds of compare-and-select (the pass is VALU-heavy: ~300 -> ~130 instructions)
-            bool fast = !A.no_fast && l >= 4 && l + 8 <= A.L;
+            bool fast = !A.no_fast && l >= 4 && l + 8 <= A.Lt;
             float c0[10], c1[10];
             if (fast) {
 #pragma unroll
                 for (int k = 3; k <= 12; ++k) {
                     int i0, i1;
-                    wunet_up_coord(j0 + k, A.L, A.up_scale, i0, i1, c0[k - 3], c1[k - 3]);
+                    wunet_up_coord(j0 + k, A.Lt, A.up_scale, i0, i1, c0[k - 3], c1[k - 3]);
                     fast = fast && i0 == ((j0 + k - 1) >> 1) && i1 == i0 + 1;
                 }
             }
@@ -424,9 +430,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             for (int k = 2; k <= 12; ++k) {                   // j = 2l-2 .. 2l+8
                 const int j = j0 + k;
                 const float dv = k < 12 ? d[k < 12 ? k : 0] : dlast;
-                if (j >= 0 && j < Lo) {
+                if (j >= 0 && j < Lot) {
                     int i0, i1; float l0, l1;
-                    wunet_up_coord(j, A.L, A.up_scale, i0, i1, l0, l1);
+                    wunet_up_coord(j, A.Lt, A.up_scale, i0, i1, l0, l1);
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
                         const float w = (i0 == l + m ? l0 : 0.0f) + (i1 == l + m ? l1 : 0.0f);
@@ -440,13 +446,16 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         for (int j = 0; j < 4; ++j) {
             float gv = g[j];
             if (!(a * z[j] + s > 0.0f)) gv *= WUNET_SLOPE;
+            const bool pad = l + j >= A.Lt;                       // row padding: no gradient, no part in the sums or bounds
+            if (pad) gv = 0.0f;
+            const float zc = pad ? 0.0f : z[j] - mu;
             go[j] = gv;
             s1 += (double)gv;
-            s2 += (double)(gv * ((z[j] - mu) * rstd));
+            s2 += (double)(gv * (zc * rstd));
             mg = fmaxf(mg, fabsf(gv));
-            mz = fmaxf(mz, fabsf(z[j] - mu));
+            mz = fmaxf(mz, fabsf(zc));
         }
-        if (FUSE) { keep_g = go; keep_z = z; keep_i = zi; have = true; }      // the thread's only iteration
+        if (FUSE) { keep_g = go; keep_z = z; keep_i = zi; keep_l = l; have = true; }      // the thread's only iteration
         else wunet_st4(A.gpre + zi, go);
     }
     block_sum2(s1, s2, red);
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         if (have) {
             wunet_f4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = k1 * keep_g[j] + k2 * keep_z[j] + k3;
+            for (int j = 0; j < 4; ++j) o[j] = keep_l + j < A.Lt ? k1 * keep_g[j] + k2 * keep_z[j] + k3 : 0.0f;
             wunet_st4(A.gpre + keep_i, o);
         }
         return;
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float
 template <int K>
 __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* x, const float* w, const float* bias, float* out,
                                                                     float* stats, int B, int Cout, int L, int logL,
-                                                                    const float* ev_a, const float* ev_s, float* xrows)
+                                                                    const float* ev_a, const float* ev_s, float* xrows, int Lt)
 {
     constexpr int PAD = K / 2, NX = ((8 + 4 + PAD + 3) / 4) * 4;          // aligned window [l0 - 8, l0 + NX - 8)
     static_assert(PAD <= 8 && NX >= 8 + 4 + PAD, "window");
@@ -609,6 +618,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
     const size_t p = ((size_t)blockIdx.x * WUNET_THREADS + threadIdx.x) * 4;
     const int b = (int)(p >> logL), l0 = (int)(p & (size_t)(L - 1));
     const bool live = b < B;
+    const bool counted = live && l0 < Lt;       // row padding (Lt = the samples that exist, a multiple of 4 at this level: all four or none
+                                                // of the thread's) is computed and stored - finite values - but not counted
     float xv[NX];
 #pragma unroll
     for (int v = 0; v < NX / 4; ++v) {
@@ -628,8 +639,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[j] = fmaf(wv, xv[8 - PAD + t + j], acc[j]);
         }
-        float s1 = live ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0f;
-        float s2 = live ? (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]) : 0.0f;
+        float s1 = counted ? (acc[0] + acc[1]) + (acc[2] + acc[3]) : 0.0f;
+        float s2 = counted ? (acc[0] * acc[0] + acc[1] * acc[1]) + (acc[2] * acc[2] + acc[3] * acc[3]) : 0.0f;
         if (live) {
             const float bv = bias ? bias[co] : 0.0f;
             wunet_f4 o;
@@ -694,7 +705,9 @@ struct PrepArgs {
     const float* z1; const float* a1; const float* s1;   // skip producer (decoder only)
     float* x;                                            // [B][C0+C1][L]
     int B, C0, C1, L, logL;
-    float up_scale;                                      // (float)(L/2-1)/(L-1)
+    float up_scale;                                      // (float)(Lt/2-1)/(Lt-1)
+    int Lt;                                              // samples of a row that exist (<= L, the power-of-two row stride): lengths m*2^n
+                                                         // are carried in rows padded to the next power of two, the padding holds zeros
 };
 
 __global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
@@ -711,6 +724,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
         float4 o;
         o.x = wunet_lrelu(a * u.x + s); o.y = wunet_lrelu(a * u.z + s);
         o.z = wunet_lrelu(a * v.x + s); o.w = wunet_lrelu(a * v.z + s);
+        if (4 * l4 + 3 >= A.Lt) {                                // row padding: zeros (the conv's zero padding at the true end of the row)
+            if (4 * l4 >= A.Lt) o.x = 0.0f;
+            if (4 * l4 + 1 >= A.Lt) o.y = 0.0f;
+            if (4 * l4 + 2 >= A.Lt) o.z = 0.0f;
+            o.w = 0.0f;
+        }
         reinterpret_cast<float4*>(A.x)[i] = o;
     }
 }
@@ -733,7 +752,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, i
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 int i0, i1; float l0, l1;
-                wunet_up_coord(4 * l4 + j, Lh, A.up_scale, i0, i1, l0, l1);
+                wunet_up_coord(4 * l4 + j, A.Lt >> 1, A.up_scale, i0, i1, l0, l1);
                 r[j] = l0 * wunet_lrelu(a * zr[i0] + s) + l1 * wunet_lrelu(a * zr[i1] + s);
             }
             o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
@@ -744,6 +763,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, i
             o.x = wunet_lrelu(a * v.x + s); o.y = wunet_lrelu(a * v.y + s);
             o.z = wunet_lrelu(a * v.z + s); o.w = wunet_lrelu(a * v.w + s);
         }
+        if (4 * l4 + 3 >= A.Lt) {                                // row padding: zeros
+            if (4 * l4 >= A.Lt) o.x = 0.0f;
+            if (4 * l4 + 1 >= A.Lt) o.y = 0.0f;
+            if (4 * l4 + 2 >= A.Lt) o.z = 0.0f;
+            o.w = 0.0f;
+        }
         reinterpret_cast<float4*>(A.x + ((size_t)b * C + c) * A.L)[l4] = o;
     }
 }
@@ -751,7 +776,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, i
 // g_z = k1*g + k2*z + k3 (BatchNorm backward folded to three per-channel coefficients), materialised once
 // per layer for its data-gradient and weight-gradient GEMMs
 __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
-                                                                        const float* k3, int C, int logL, size_t n4, float* gz)
+                                                                        const float* k3, int C, int logL, size_t n4, float* gz, int Lt)
 {
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
         const int c = (int)((i >> (logL - 2)) % (size_t)C);
@@ -760,6 +785,13 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const flo
         float4 o;
         o.x = a * gv.x + b * zv.x + d; o.y = a * gv.y + b * zv.y + d;
         o.z = a * gv.z + b * zv.z + d; o.w = a * gv.w + b * zv.w + d;
+        const int l = (int)((i << 2) & (((size_t)1 << logL) - 1));
+        if (l + 3 >= Lt) {                                       // row padding: no gradient
+            if (l >= Lt) o.x = 0.0f;
+            if (l + 1 >= Lt) o.y = 0.0f;
+            if (l + 2 >= Lt) o.z = 0.0f;
+            o.w = 0.0f;
+        }
         reinterpret_cast<float4*>(gz)[i] = o;
     }
 }

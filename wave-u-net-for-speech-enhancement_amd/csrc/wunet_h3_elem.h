@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3R
 // block 0 publishes {scale, 1/scale} for the GEMMs.  One thread per (channel group, 4 samples).
 __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                      const float* k3, const float* bound, float* sc, wunet_half* hi,
-                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int bf)
+                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int bf, int Lt)
 {
     __shared__ float red[WUNET_THREADS];
     float m = 0.0f;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                 const wunet_f4 gv = wunet_ld4(g + o), zv = wunet_ld4(z + o);
                 const float a = k1[ok ? c : 0], bb = k2[ok ? c : 0], d = k3[ok ? c : 0];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[e][j] = ok ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;
+                for (int j = 0; j < 4; ++j) v[e][j] = (ok && 4 * l4 + j < Lt) ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;     // (row padding: no gradient)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -335,6 +335,7 @@ struct PrepH3Args {
     const float* xb0; const float* xb1; float* xsc;
     const float* ssb0; const float* ssb1;
     int bf;              // bf16 mode: one bf16 word per value into xh / sh, the lo arrays are not written
+    int Lt;              // samples of a row that exist (<= L, the power-of-two row stride; PrepArgs::Lt); the skip destination has 2 Lt
 };
 
 // One thread = 8 channels of ONE sample, consecutive lanes = consecutive samples: every store instruction of a wave
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
         const size_t row = (size_t)b * A.C8 + c8;
         int i0 = 0, i1 = 0;
         float l0 = 0.0f, l1 = 0.0f;
-        if (KIND != 0) wunet_up_coord(p, Lh, A.up_scale, i0, i1, l0, l1);     // once for the 8 channels
+        if (KIND != 0) wunet_up_coord(p, A.Lt >> 1, A.up_scale, i0, i1, l0, l1);     // once for the 8 channels
         // skip half of the decoder input at the producer's resolution (SKIP_DST): the wave's 64 samples p0 .. p0+63 come from the
         // 128 source samples 2*p0 .. 2*p0+127; this lane activates and writes source samples 2*p0+lane and 2*p0+64+lane
         // (lane-contiguous again).  Rows shorter than a wave: the thread's own pair 2p, 2p+1.
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                     const float u0 = wunet_lrelu(av[e] * za[e] + sv[e]), u1 = wunet_lrelu(av[e] * zb[e] + sv[e]);
                     v = from_up[e] ? l0 * u0 + l1 * u1 : u0;
                 }
-                if (c >= C) v = 0.0f;
+                if (c >= C || p >= A.Lt) v = 0.0f;                // (channels beyond C, row padding: zeros)
                 wunet_half a, d;
                 wunet_split_rt(A.bf, xs_ * v, a, d);
                 wunet_put_half(h, e, a);
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = c8 * 8 + e;
-                    const float v = c < C ? wunet_lrelu(av[e] * zq[k][e] + sv[e]) : 0.0f;
+                    const float v = (c < C && q < 2 * A.Lt) ? wunet_lrelu(av[e] * zq[k][e] + sv[e]) : 0.0f;
                     wunet_half a, d;
                     wunet_split_rt(A.bf, ss_ * v, a, d);
                     wunet_put_half(h, e, a);
