@@ -306,7 +306,10 @@ struct wunet_ctx {
     // side stream for the weight-gradient GEMMs (off the backward's critical chain): one per device the ctx is used on, created
     // lazily under the lock and never replaced, so replicas of one shape on several devices (or threads) do not disturb each other.
     // Everything else in the ctx is immutable after wunet_create / wunet_set_h3.
-    struct Side { hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+    struct Side {
+        hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+        const void* packed_ws = nullptr;      // the workspace whose backward weight packs the last training forward enqueued on `stream`
+    };
     std::map<int, Side> side;
     std::mutex side_lock;
 };
@@ -709,6 +712,47 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     return 0;
 }
 
+// Flipped / transposed weight packs of every data gradient (fp32 fragment packs of the fp32 layers, hi / lo packs of the split
+// layers): two launches that read only the weights (and the forward's weight maxima)
+int launch_backward_packs(wunet_ctx* c, const float* const* params, float* ws, hipStream_t st)
+{
+    const int NL = c->NL;
+    PackTable tab{};
+    int nd = 0;
+    for (int i = 1; i < NL; ++i) {
+        const LayerPlan& l = c->ly[i];
+        if (l.h3d) continue;                       // data gradient on the split pack
+        PackDesc& d = tab.d[nd++];
+        d.w = params[4 * i]; d.dst = ws + c->wpkb_off + l.d_wpk;
+        d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cin; d.CP = l.d.cp; d.mtiles = l.d.mtiles_p; d.transposed = 1;
+    }
+    if (nd > 0) {
+        WUNET_LAUNCH(pack_weights_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
+        WUNET_CHECK_LAUNCH();
+    }
+    if (c->h3) {
+        PackH3Table t3{};
+        int n3 = 0;
+        wunet_half* wh = reinterpret_cast<wunet_half*>(ws + c->h3_wb_hi);
+        wunet_half* wl = reinterpret_cast<wunet_half*>(ws + c->h3_wb_lo);
+        for (int i = 1; i < NL; ++i) {
+            const LayerPlan& l = c->ly[i];
+            if (!l.h3d) continue;
+            PackH3Desc& d = t3.d[n3++];
+            d.w = params[4 * i]; d.hi = wh + l.h3d_wpk; d.lo = wl + l.h3d_wpk;
+            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
+            d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i;      // the forward's maxima: the weights have not changed since
+            d.wsc = l.h3f ? nullptr : ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
+            d.bf = c->bf;
+        }
+        if (n3 > 0) {
+            WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), n3), dim3(WUNET_THREADS), 0, st, t3);
+            WUNET_CHECK_LAUNCH();
+        }
+    }
+    return 0;
+}
+
 // the side stream + fork / join events of the CURRENT device (nullptr + error text on failure)
 wunet_ctx::Side* side_for_current_device(wunet_ctx* c)
 {
@@ -723,7 +767,8 @@ wunet_ctx::Side* side_for_current_device(wunet_ctx* c)
     const unsigned evf = hipEventDisableTiming | (getenv("WUNET_EVENT_SYSFENCE") ? 0u : (unsigned)hipEventDisableSystemFence);
     if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sd.ev_fork, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.ev_join, evf) != hipSuccess) {
+        hipEventCreateWithFlags(&sd.ev_join, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ev_pack, evf) != hipSuccess) {
         fail(WUNET_E_RUNTIME, "cannot create the side stream of device %d", dev);
         return nullptr;
     }
@@ -792,7 +837,7 @@ void wunet_destroy(wunet_ctx* ctx)
 {
     if (!ctx) return;
     for (auto& kv : ctx->side) {
-        hipStreamDestroy(kv.second.stream); hipEventDestroy(kv.second.ev_fork); hipEventDestroy(kv.second.ev_join);
+        hipStreamDestroy(kv.second.stream); hipEventDestroy(kv.second.ev_fork); hipEventDestroy(kv.second.ev_join); hipEventDestroy(kv.second.ev_pack);
     }
     delete ctx;
 }
@@ -818,7 +863,6 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                   long long* const* nbt, int training, int save_for_backward, void* workspace, float* enhanced, void* stream)
 {
     if (!c || !noisy || !params || !running || !nbt || !workspace || !enhanced) return fail(WUNET_E_ARG, "null argument");
-    (void)save_for_backward;   // everything the backward needs (z, BN statistics, conv inputs) lives in the forward segment
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
     // The skip half of each decoder input only depends on an encoder level and could run on the side stream during
@@ -888,6 +932,21 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         if (nd > 0) {
             WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
             WUNET_CHECK_LAUNCH();
+        }
+    }
+    // The backward's flipped / transposed weight packs only depend on the weights (and on the maxima h3_scales_kernel has just
+    // taken): a training forward that will be followed by a backward enqueues them on the side stream now, beside the first convs,
+    // instead of leaving two launches at the head of the backward's critical path (WUNET_NO_EARLY_BPACK=1: A/B switch).
+    if (training && save_for_backward && c->NL > 1) {
+        static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr || getenv("WUNET_NO_EARLY_BPACK") != nullptr;
+        wunet_ctx::Side* side = (no_side || g_prof_on) ? nullptr : side_for_current_device(c);
+        if (side) {
+            if (hipEventRecord(side->ev_fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->ev_fork, 0) != hipSuccess)
+                return fail(WUNET_E_RUNTIME, "fork onto the side stream failed");
+            const int rc = launch_backward_packs(c, params, ws, side->stream);
+            if (rc) return rc;
+            if (hipEventRecord(side->ev_pack, side->stream) != hipSuccess) return fail(WUNET_E_RUNTIME, "recording the pack event failed");
+            side->packed_ws = workspace;
         }
     }
     for (int i = 0; i < c->NL; ++i) {
@@ -1110,39 +1169,15 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
     }
 
     if (layer_end == NL) {
-        // flipped/transposed weights for every data gradient (one launch)
-        PackTable tab{};
-        int nd = 0;
-        for (int i = 1; i < NL; ++i) {
-            const LayerPlan& l = c->ly[i];
-            if (l.h3d) continue;                       // data gradient on the split pack
-            PackDesc& d = tab.d[nd++];
-            d.w = params[4 * i]; d.dst = ws + c->wpkb_off + l.d_wpk;
-            d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cin; d.CP = l.d.cp; d.mtiles = l.d.mtiles_p; d.transposed = 1;
-        }
-        if (nd > 0) {
-            WUNET_LAUNCH(pack_weights_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
-            WUNET_CHECK_LAUNCH();
-        }
-        if (c->h3) {
-            PackH3Table t3{};
-            int n3 = 0;
-            wunet_half* wh = reinterpret_cast<wunet_half*>(ws + c->h3_wb_hi);
-            wunet_half* wl = reinterpret_cast<wunet_half*>(ws + c->h3_wb_lo);
-            for (int i = 1; i < NL; ++i) {
-                const LayerPlan& l = c->ly[i];
-                if (!l.h3d) continue;
-                PackH3Desc& d = t3.d[n3++];
-                d.w = params[4 * i]; d.hi = wh + l.h3d_wpk; d.lo = wl + l.h3d_wpk;
-                d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
-                d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i;      // the forward's maxima: the weights have not changed since
-                d.wsc = l.h3f ? nullptr : ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
-                d.bf = c->bf;
-            }
-            if (n3 > 0) {
-                WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), n3), dim3(WUNET_THREADS), 0, st, t3);
-                WUNET_CHECK_LAUNCH();
-            }
+        // flipped/transposed weights for every data gradient: already enqueued on the side stream by the training forward of this
+        // workspace (they only depend on the weights: off the critical path), else packed here
+        if (side->packed_ws == workspace && sd != st) {
+            side->packed_ws = nullptr;
+            if (hipStreamWaitEvent(st, side->ev_pack, 0) != hipSuccess) return fail(WUNET_E_RUNTIME, "waiting for the weight packs failed");
+        } else {
+            side->packed_ws = nullptr;
+            const int rc = launch_backward_packs(c, params, ws, st);
+            if (rc) return rc;
         }
         // head backward: gh = gout * tanh', d wh, d bh
         const LayerPlan& l = c->ly[NL - 1];
