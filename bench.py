@@ -197,7 +197,11 @@ def main():
     adam_cls = torch.optim.Adam if args.torch_adam else optim_mod.FusedAdam     # reference train.py:31-35
     opt = adam_cls(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
     if world > 1:
-        model.grad_sync = parallel.GradSync(n_buckets=4)
+        # bucketed RCCL all-reduce inside the backward; the 1/world of the average is folded into the fused Adam step
+        # (same rounding, four launches and 2 x 40 MB of traffic less per step) unless torch's optimiser is used
+        model.grad_sync = parallel.GradSync(n_buckets=4, scale_in_optimizer=not args.torch_adam)
+        if not args.torch_adam:
+            opt.grad_scale = 1.0 / world
     noisy, clean = synthetic_batch(args.batch, device, seed=rank, frame=args.frame)
     default_net = args.layers == N_LAYERS and args.frame == FRAME
     fwd_flop, fwd_bytes = net_flops_bytes(args.layers, CI, args.frame)
