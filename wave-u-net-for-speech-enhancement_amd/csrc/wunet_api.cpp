@@ -390,7 +390,10 @@ void plan_h3_wgrad(LayerPlan& l, int B)
     // single blocks (weight gradients 1.25 -> 1.14 ms per step; the register-staged kernel preferred 5-6 m-tiles)
     // per-layer sweep (profiles/r1_h3_rows_per_wave_sweep.txt): 4 where 5 taps divide evenly at >= 256 samples
     // (decoder.7: 79 -> 68 us); 2 on the short 15-tap levels (encoder.6/7/9: 44 -> 39, 32 -> 29, 21 -> 18 us)
-    const char* w_order = (l.taps == 5 && l.L >= 256 && mt % 4 == 0) ? "432" : (l.taps == 15 && l.L <= 256) ? "2" : "32";
+    // (round-2 sweep, profiles/r2_wgrad_rows_sweep.txt: 5 m-tiles in one block - no padded rows - win on the 15-tap layer with
+    // Cout = 80 .. 72 at >= 1024 samples (encoder.2: 118 -> 106 us) although that kernel runs one block per CU)
+    const char* w_order = (l.taps == 5 && l.L >= 256 && mt % 4 == 0) ? "432" : (l.taps == 15 && l.L <= 256) ? "2" :
+                          (l.taps == 15 && mt == 5 && l.L >= 1024) ? "532" : "32";
     l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", w_order);
     l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
     l.h3w_nblocks = (l.cin + cib - 1) / cib;
