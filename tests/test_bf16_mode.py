@@ -35,7 +35,9 @@ def autocast_reference(sd, noisy, clean, n, ci, loss="mse"):
     return out.detach().float().numpy(), {k: v.grad.numpy() for k, v in tsd.items() if v.requires_grad}
 
 
-@pytest.mark.parametrize("net", [(3, 16, 3, 1024), (4, 16, 5, 1024), (2, 24, 2, 1024)], ids=lambda c: "n%dci%dB%dT%d" % c)
+@pytest.mark.parametrize("net", [(3, 16, 3, 1024), (4, 16, 5, 1024), (2, 24, 2, 1024),
+                                 (3, 16, 2, 768)],           # 768 = 3 * 2^8 samples: rows padded to 1024 / 512 / 256 / 128
+                         ids=lambda c: "n%dci%dB%dT%d" % c)
 def test_bf16_mode_is_at_least_as_accurate_as_the_reference_under_autocast(net):
     n, ci, B, T = net
     sd = plan.golden_state(n, ci, 0)

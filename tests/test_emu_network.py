@@ -179,11 +179,12 @@ def test_measurement_switches_are_bit_identical(switch, h3, cfg, monkeypatch):
         assert np.array_equal(a, b)
 
 
-def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3):
+@pytest.mark.parametrize("T", [1024, 768])        # 768 = 3 * 2^8: padded rows, the padded copies of input / result / gradient
+def test_fp16_split_backward_in_buckets_equals_whole(emu_engine_h3, T):
     """wunet_backward_range in three buckets == one wunet_backward, bit for bit, with the split kernels forced on (per-layer
     gradient scales and split weight packs have to survive the bucket boundaries) - the path GradSync drives."""
     eng = emu_engine_h3
-    n, ci, B, T = 2, 24, 2, 1024
+    n, ci, B = 2, 24, 2
     sd = plan.golden_state(n, ci, 0)
     noisy, _ = plan.golden_batch(B, T, 0)
     names, bnames = plan.param_names(n, ci), plan.buffer_names(n, ci)
