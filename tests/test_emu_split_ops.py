@@ -21,6 +21,11 @@ def rel_norm(a, r):
     (5, 16, 56, 64, 15, 1.0, 1.0),         # four-item tiles
     (9, 72, 40, 32, 5, 1e3, 1e-3),         # eight-item tiles: 2 items under one wave
     (17, 40, 72, 16, 15, 1.0, 1.0),        # sixteen-item tiles: 4 items under one wave
+    # K tails of conv_h3d_kernel (channel groups left over after the last chunk of 32: one tail stage per group, taps spread over
+    # the K quarters of the MFMA) - the cases above already hold 1 / 2 / 3 left-over groups with and without a full chunk; here
+    # behind two full chunks, split K with splits that start inside the tail, and a 5-tap tail behind three chunks
+    (2, 72, 80, 512, 15, 1.0, 1.0),        # 9 groups forward (2 chunks + 1), 10 backward (2 chunks + 2)
+    (3, 104, 24, 256, 5, 1.0, 1.0),        # 13 groups forward: 3 chunks + a 5-tap tail stage of 2 steps
 ])
 def test_split_ops_vs_oracle(B, Cin, Cout, L, K, xs, ws):
     rng = np.random.default_rng(B * 1000 + Cin)

@@ -4,6 +4,7 @@
 
 #define WUNET_XCASE(T, M, S)                                                                               \
     if (taps == T && mrep == M && nseg == S) {                                                             \
+        if (!WUNET_H3D_HAS_TAIL(M, S) && a.NFS != a.NS) return -3;      /* pack with a K tail, kernel without */ \
         if (bf) {                                                                                          \
             if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<T, M, S, true>), smem) != 0) return -2;               \
             WUNET_LAUNCH((conv_h3d_kernel<T, M, S, true>), grid, dim3(WUNET_THREADS), smem, st, a);        \
@@ -16,6 +17,7 @@
 
 #define WUNET_ILCASE(T, M)                                                                                 \
     if (il && !bf && taps == T && mrep == M && nseg == 1) {                                                \
+        if (a.NFS != a.NS) return -3;                                                                      \
         if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<T, M, 1, false, true>), smem) != 0) return -2;            \
         WUNET_LAUNCH((conv_h3d_kernel<T, M, 1, false, true>), grid, dim3(WUNET_THREADS), smem, st, a);     \
         return 0;                                                                                          \
@@ -29,5 +31,6 @@ int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim
     WUNET_XCASE(15, 2, 2) WUNET_XCASE(15, 3, 2) WUNET_XCASE(5, 2, 2) WUNET_XCASE(5, 3, 2)
     WUNET_XCASE(15, 2, 4) WUNET_XCASE(15, 3, 4) WUNET_XCASE(5, 2, 4) WUNET_XCASE(5, 3, 4)
     WUNET_XCASE(15, 2, 8) WUNET_XCASE(15, 3, 8) WUNET_XCASE(5, 2, 8) WUNET_XCASE(5, 3, 8)
+    WUNET_XCASE(15, 2, 16) WUNET_XCASE(15, 3, 16) WUNET_XCASE(5, 2, 16) WUNET_XCASE(5, 3, 16)
     return -1;
 }

@@ -275,6 +275,7 @@ struct LayerPlan {
     // fp16-split path
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
+    int h3f_ntt, h3d_ntt;    // K tail of conv_h3d_kernel: steps of a tail stage (0: the last chunk is padded to 32 channels)
     int h3f_sps, h3d_sps;         // K stages per split of conv_h3_kernel (the split count is f.ksplit / d.ksplit)
     int first;                    // encoder[0] (Cin = 1): direct fp32 kernel (conv_first_kernel)
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
@@ -365,9 +366,31 @@ int h3_stages_per_split(int blocks, int nstage)
 // Tiling of conv_h3_kernel for one GEMM (rows x B*L positions, K = kch channels x taps): accumulator rows per wave, padded
 // m-tiles, chunks of 32 K channels, K stages per split and the split count.  Shared by the network planner and the
 // single-op entry points, so a geometry gets the same kernel instantiation either way.
-struct H3ConvPlan { int mrep, mtp, nch, sps, ksplit, ntiles; };
+struct H3ConvPlan { int mrep, mtp, nch, sps, ksplit, ntiles, ntt; };
+bool h3_conv_is_dma(int L);
+bool h3_conv_is_paired(int B, int L);
 
-H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* order_env)
+// K tail of conv_h3d_kernel: with c8 = 4 nfull + t1 groups of 8 K channels, the t1 left-over groups run one tail stage each (the taps
+// spread over the four K quarters of the MFMA: ceil(taps / 4) steps) instead of one chunk padded with zeros (taps steps).  Worth it
+// for 15 taps with any tail (4 t1 steps instead of 15), for 5 taps with one left-over group (2 instead of 5).
+// Returns the steps of a tail stage, 0 without a tail.  WUNET_H3_KTAIL=0: A/B switch (the padded chunk everywhere)
+int h3_tail_steps(int B, int L, int kch, int taps, int bf)
+{
+    const char* kt = getenv("WUNET_H3_KTAIL");          // (read when a context is planned)
+    const int on = kt ? atoi(kt) : 1;
+    const char* ile = getenv("WUNET_H3_IL");
+    const int t1 = ((kch + 7) / 8) & 3;
+    if (!on || !h3_conv_is_dma(L) || (!bf && h3_conv_is_paired(B, L)) || (ile && atoi(ile) != 0)) return 0;
+    return taps == 15 ? (t1 ? 4 : 0) : (t1 == 1 ? 2 : 0);
+}
+// stages of the K loop: full chunks * tap groups + tail stages
+int h3_stage_count(int kch, int taps, int ntt)
+{
+    const int c8 = (kch + 7) / 8;
+    return ntt ? (c8 / 4) * (taps / 5) + (c8 & 3) : ((c8 + 3) / 4) * (taps / 5);
+}
+
+H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* order_env, int bf = 0)
 {
     H3ConvPlan p{};
     const long long posn = (long long)B * L;
@@ -377,8 +400,11 @@ H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* o
     p.mrep = pick_mrep_h3(mt, L >= 256 ? order_env : nullptr, h3_order(taps, L, p.ntiles, mt));
     p.mtp = round_up(mt, p.mrep);
     p.nch = (c8 + 3) / 4;
-    p.sps = h3_stages_per_split(p.ntiles * (p.mtp / p.mrep), p.nch * ntg);
-    p.ksplit = (p.nch * ntg + p.sps - 1) / p.sps;
+    p.ntt = (p.mrep < 4 && L >= 32) ? h3_tail_steps(B, L, kch, taps, bf) : 0;      // (WUNET_H3D_HAS_TAIL: the shapes at the register limit go without)
+    const int ns = h3_stage_count(kch, taps, p.ntt);
+    p.sps = h3_stages_per_split(p.ntiles * (p.mtp / p.mrep), ns);
+    p.ksplit = (ns + p.sps - 1) / p.sps;
+    (void)ntg;
     return p;
 }
 
@@ -445,14 +471,14 @@ void layout_workspace(wunet_ctx* c)
             l.h3w = l.h3d;
             l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
             if (l.h3f) {
-                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cout, l.cin, l.taps, "WUNET_H3_ORDER");
-                l.h3f_mrep = p.mrep; l.h3f_mtp = p.mtp; l.h3f_nch = p.nch; l.h3f_sps = p.sps;
+                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cout, l.cin, l.taps, "WUNET_H3_ORDER", c->bf);
+                l.h3f_mrep = p.mrep; l.h3f_mtp = p.mtp; l.h3f_nch = p.nch; l.h3f_sps = p.sps; l.h3f_ntt = p.ntt;
                 l.f.ksplit = p.ksplit;
                 l.f.grid_x = p.ntiles;                 // one statistics row per tile (f_rows below)
             }
             if (l.h3d) {
-                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cin, l.cout, l.taps, "WUNET_H3D_ORDER");
-                l.h3d_mrep = p.mrep; l.h3d_mtp = p.mtp; l.h3d_nch = p.nch; l.h3d_sps = p.sps;
+                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cin, l.cout, l.taps, "WUNET_H3D_ORDER", c->bf);
+                l.h3d_mrep = p.mrep; l.h3d_mtp = p.mtp; l.h3d_nch = p.nch; l.h3d_sps = p.sps; l.h3d_ntt = p.ntt;
                 l.d.ksplit = p.ksplit;
             }
             if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
@@ -589,13 +615,13 @@ bool h3_conv_is_paired(int B, int L)
     return pair_env && L >= 256 && (posn & 511) == 0;
 }
 
-// conv_h3d_kernel (DMA-staged, pipelined, persistent) runs instead of conv_h3_kernel: every tile shape but the 16-sample level's
-// (16 items per tile: its x image alone is 64 KB)
+// conv_h3d_kernel (DMA-staged, pipelined, persistent) runs instead of conv_h3_kernel (the 16-sample level, 16 items per tile with a
+// 64 KB x image, at one block per CU)
 bool h3_conv_is_dma(int L)
 {
     const char* e = getenv("WUNET_H3_XDMA");            // A/B switch (read per launch: tests toggle it): 0 = off, 2 = un-segmented tiles only
     const int v = e ? atoi(e) : 1;
-    return v != 0 && L >= (v == 2 ? 256 : 32);
+    return v != 0 && L >= (v == 2 ? 256 : 16);
 }
 
 // resident conv_h3d blocks the grid is sized for: two per CU (its launch bounds); WUNET_H3_GRID overrides (tests: a few blocks walk
@@ -623,7 +649,7 @@ unsigned long long* g_h3_trace = nullptr;       // wunet_debug_set_conv_trace
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr,
-                   int bf = 0)
+                   int bf = 0, int ntt = 0)
 {
     char pname[96];
     const double posn = (double)B * L;
@@ -631,16 +657,17 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.sc2 = sc2; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
     a.ev_a = ev_a; a.ev_s = ev_s; a.xrows = xrows;
-    const int nseg = L >= 256 ? 1 : 256 / L, nstage = nch * (taps / 5);
+    const int nseg = L >= 256 ? 1 : 256 / L, nstage = h3_stage_count(kch, taps, ntt);
+    a.NS = nstage; a.NFS = ntt ? (a.C8 / 4) * (taps / 5) : nstage;
     const int ksplit = (nstage + sps - 1) / sps;
     a.stages_per_split = sps; a.split_stride = (size_t)B * rows * L;
 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     a.trace = g_h3_trace;
     // paired tiles (conv_h3p_kernel: two tiles per 512-thread block, double-buffered shared W) for L >= 256 with an even tile count
-    const bool paired = !bf && h3_conv_is_paired(B, L);     // (A/B switch: WUNET_H3_PAIR=1)
+    const bool paired = !ntt && !bf && h3_conv_is_paired(B, L);     // (A/B switch: WUNET_H3_PAIR=1)
     int rc;
-    if (!paired && h3_conv_is_dma(L)) {
+    if (ntt || (!paired && h3_conv_is_dma(L))) {         // (a pack with a K tail was laid out for this kernel)
         // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
         snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
         prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)));
@@ -653,7 +680,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
         if (gx > nitems) gx = nitems;
         const dim3 grid((unsigned)gx, (unsigned)ksplit);
         const char* ile = getenv("WUNET_H3_IL");         // A/B switch: DMA pieces interleaved with the MFMA passes (un-segmented tiles)
-        rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, ile && atoi(ile) != 0 && !g_h3_trace);
+        rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, !ntt && ile && atoi(ile) != 0 && !g_h3_trace);
     } else if (paired) {
         snprintf(pname, sizeof pname, "conv_h3p_kernel<%d, %d>", taps, mrep);
         prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
@@ -692,6 +719,7 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
         (void)zero;
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
+        { const char* e = getenv("WUNET_H3W_NOSKIP"); a.cin_active = (e && atoi(e) != 0) ? 0x7fffffff : l.cin; }     // A/B switch
         snprintf(pname, sizeof pname, bf ? "wgrad_h3d_kernel<%d, %d, bf16>" : (tp == 64 ? "wgrad_h3d_kernel<%d, %d, 64>" : "wgrad_h3d_kernel<%d, %d>"), l.taps, l.h3w_mrep);
         prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
         // two blocks per CU with a single buffer where the registers allow it (two independent blocks hide each other's
@@ -744,6 +772,7 @@ int launch_backward_packs(wunet_ctx* c, const float* const* params, float* ws, h
             PackH3Desc& d = t3.d[n3++];
             d.w = params[4 * i]; d.hi = wh + l.h3d_wpk; d.lo = wl + l.h3d_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cin; d.kch = l.cout; d.mtiles = l.h3d_mtp; d.nch = l.h3d_nch; d.transposed = 1;
+            d.ntt = l.h3d_ntt; d.nfull = ((l.cout + 7) / 8) / 4; d.ns = h3_stage_count(l.cout, l.taps, l.h3d_ntt);
             d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i;      // the forward's maxima: the weights have not changed since
             d.wsc = l.h3f ? nullptr : ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
             d.bf = c->bf;
@@ -929,6 +958,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             PackH3Desc& d = tab.d[nd++];
             d.w = params[4 * i]; d.hi = wh + l.h3f_wpk; d.lo = wl + l.h3f_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cout; d.kch = l.cin; d.mtiles = l.h3f_mtp; d.nch = l.h3f_nch; d.transposed = 0;
+            d.ntt = l.h3f_ntt; d.nfull = ((l.cin + 7) / 8) / 4; d.ns = h3_stage_count(l.cin, l.taps, l.h3f_ntt);
             d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i; d.wsc = ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
             d.bf = c->bf;
         }
@@ -1076,7 +1106,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
-                                    l.cin, l.h3f_nch, l.L, st, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf);
+                                    l.cin, l.h3f_nch, l.L, st, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf, l.h3f_ntt);
             if (rc) return rc;
         } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;
@@ -1349,7 +1379,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
                                     ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2,
                                     split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st, nullptr, nullptr,
-                                    nullptr, c->bf);
+                                    nullptr, c->bf, l.h3d_ntt);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
             if (split) {
@@ -1662,12 +1692,13 @@ int op_conv_split_common(const float* x, const float* w, const float* bias, floa
         PackH3Table tab{};
         PackH3Desc& d = tab.d[0];
         d.w = w; d.hi = wh.h(); d.lo = wl.h(); d.Cout = Cout; d.Cin = Cin; d.taps = K; d.rows = rows; d.kch = kch; d.mtiles = p.mtp; d.nch = p.nch;
+        d.ntt = p.ntt; d.nfull = ((kch + 7) / 8) / 4; d.ns = h3_stage_count(kch, K, p.ntt);
         d.transposed = transposed; d.wmax = wmax; d.wsc = wslot + 2;
         WUNET_LAUNCH(pack_h3_kernel, dim3(64, 1), dim3(WUNET_THREADS), 0, st, tab);
     }
     const bool split = p.ksplit > 1;
     rc = launch_conv_h3(K, p.mrep, p.mtp, p.sps, xh.h(), xl.h(), wh.h(), wl.h(), split ? nullptr : bias, xslot, wslot + 2,
-                        split ? part.f() : out, nullptr, B, rows, kch, p.nch, L, st);
+                        split ? part.f() : out, nullptr, B, rows, kch, p.nch, L, st, nullptr, nullptr, nullptr, 0, p.ntt);
     if (!rc && split) {
         size_t blocks = (nout + WUNET_THREADS - 1) / WUNET_THREADS;
         if (blocks > 2048) blocks = 2048;

@@ -42,6 +42,7 @@ struct ConvH3Args {
     const float* ev_a; const float* ev_s; float* xrows;
     unsigned long long* trace;                    // nullptr, or [gridDim.x][64] shader-clock stamps of the block's phases (conv_h3d_kernel; tools/conv_trace.py)
     int B, Cout, C8, NCH, L, logL;
+    int NS, NFS;                                  // conv_h3d_kernel: K stages of the pack, the first NFS of them full (TG taps of a chunk); the rest: K tail
     int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
     size_t split_stride;                          // floats between the partial results of two splits
@@ -704,6 +705,7 @@ struct WgradH3dArgs {
     float* part;
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
     size_t part_stride;
+    int cin_active;           // waves whose input channels start at or beyond it skip their MFMAs (= Cin; A/B switch: INT_MAX)
 };
 
 // TP = 64 with DB: chunks of 64 positions, double buffered within the LDS budget of ONE 128-position buffer - two blocks per CU AND
@@ -792,6 +794,10 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
 #pragma unroll
         for (int tw = 0; tw < TW; ++tw) acc[mt][tw] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
+    // a wave whose 16 input channels all lie beyond Cin (the last channel block of a Cin that is not a multiple of 16 WG) leaves the
+    // matrix pipe of its SIMD to the other resident block; its zero accumulators are stored like any other (the reduce kernel
+    // drops those columns)
+    const bool active = wunet_uniform(ci0 + grp * 16 < A.cin_active ? 1 : 0) != 0;
     if (DB && kbeg < kend) WUNET_WH3D_DMA(kbeg, 0)
     for (long long k = kbeg; k < kend; ++k) {
         const int cur = DB ? (int)((k - kbeg) & 1) : 0;
@@ -807,6 +813,7 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
         // waits for it with lgkmcnt(0): one LDS round trip per tap with nothing from this wave in the matrix pipe); the MFMAs of a
         // tap are issued pass-major (per accumulator the order lo*hi, hi*lo, hi*hi is unchanged: bit-identical results)
         constexpr int KS = TP / 32;
+        if (!active) continue;                     // (it only took part in the staging)
         wunet_h8 ah[2][M_REP], al[2][M_REP], bh[2], bl[2];
 #define WUNET_WH3D_LOAD_A(BUF_, KS_)                                                                              \
     _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \

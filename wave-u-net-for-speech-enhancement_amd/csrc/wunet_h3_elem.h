@@ -549,7 +549,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
 }
 
 // ---------------------------------------------------------------------------- weight pack
-// dst[mt][chunk][tap][q][i][e] = W(row = mt*16+i, k-channel = chunk*32+q*8+e, tap); forward: W = w[row][kch][tap];
+// dst[mt][stage][slot][q][i][e], 5 slots per stage.  Full stage (chunk ch of 32 K channels, tap group tg; stage = ch * taps/5 + tg):
+// W(row = mt*16+i, k-channel = ch*32+q*8+e, tap = tg*5+slot) - i.e. [mt][chunk][tap][q][i][e].  Tail stage g (ntt > 0; after the
+// nfull full chunks: one per left-over group of 8 channels, conv_h3d_kernel's K tail): W(row, k-channel = nfull*32+g*8+e,
+// tap = q*ntt+slot) for slot < ntt, zero for slot >= ntt or tap >= taps.  Forward: W = w[row][kch][tap];
 // data gradient (transposed): W = w[kch][row][TAPS-1-tap].  hi and lo arrays.
 struct PackH3Desc {
     const float* w;
@@ -562,13 +565,16 @@ struct PackH3Desc {
     const float* wmax;     // WUNET_WMAX_PARTS partial maxima of |w| (h3_scales_kernel)
     float* wsc;            // {scale, 1/scale} of the packed weights, published by block 0 (nullptr: another pack of this layer did)
     int bf;                // bf16 mode: one bf16 word per weight into hi
+    int ntt;               // 0: every chunk full stages (nch chunks); else the steps of a tail stage, and
+    int nfull, ns;         // ... the full chunks / the stages in all
 };
 struct PackH3Table { PackH3Desc d[WUNET_MAX_CONV_LAYERS]; };
 
 __global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
 {
     const PackH3Desc& d = tab.d[blockIdx.y];
-    const int total = d.mtiles * d.nch * d.taps * 512;
+    const int ntg = d.taps / 5, ns = d.ntt ? d.ns : d.nch * ntg, nfs = d.ntt ? d.nfull * ntg : ns;
+    const int total = d.mtiles * ns * 5 * 512;
     // the layer's weight scale: max |w| -> [2^13, 2^14); every block derives the same value from the partial maxima
     __shared__ float wsc_sh[2];
     if (threadIdx.x < 64) {
@@ -587,11 +593,14 @@ __global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
     for (int idx = blockIdx.x * WUNET_THREADS + threadIdx.x; idx < total; idx += gridDim.x * WUNET_THREADS) {
         const int e = idx & 7, i = (idx >> 3) & 15, q = (idx >> 7) & 3;
         int r = idx >> 9;
-        const int t = r % d.taps; r /= d.taps;
-        const int ch = r % d.nch, mt = r / d.nch;
-        const int row = mt * 16 + i, k = ch * 32 + q * 8 + e;
+        const int slot = r % 5; r /= 5;
+        const int stg = r % ns, mt = r / ns;
+        const int row = mt * 16 + i;
+        int k, t;
+        if (stg < nfs) { k = (stg / ntg) * 32 + q * 8 + e; t = (stg % ntg) * 5 + slot; }
+        else { k = d.nfull * 32 + (stg - nfs) * 8 + e; t = slot < d.ntt ? q * d.ntt + slot : d.taps; }
         float v = 0.0f;
-        if (row < d.rows && k < d.kch)
+        if (row < d.rows && k < d.kch && t < d.taps)
             v = d.transposed ? d.w[((size_t)k * d.Cin + row) * d.taps + (d.taps - 1 - t)] : d.w[((size_t)row * d.Cin + k) * d.taps + t];
         wunet_half a, b;
         wunet_split_rt(d.bf, wscale * v, a, b);

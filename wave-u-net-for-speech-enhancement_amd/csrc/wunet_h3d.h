@@ -12,6 +12,11 @@
 //     LDS-DMA" cannot serialise the pipeline again.
 //   * blocks are persistent: a block walks work items (position tile, row block) blockIdx.x, blockIdx.x + gridDim.x, ...; the first
 //     stage of the next item is fetched under the last stage and the epilogue of the current one.
+//   * K tail (A.NFS < A.NS): the channel groups left over after the last full chunk of 32 channels are not padded to a chunk (15 steps
+//     for 1-3 groups of 8 channels with 3/4 .. 1/4 of every MFMA multiplying zeros) but run one TAIL stage each: the four K quarters
+//     of an MFMA carry four TAP ranges of the one group (quarter q: taps q*NTT .. q*NTT + NTT - 1, NTT = ceil(TAPS / 4); the weight
+//     pack holds zeros for taps >= TAPS), i.e. 4 steps per group for 15 taps, 2 for 5.  Same LDS images: the tail chunk's x tile is
+//     staged like any other, a quarter just reads its columns NTT*q further right.
 // The MFMAs of a tap are issued pass-major (all accumulators' lo*hi, then hi*lo, then hi*hi): 4*M_REP independent MFMAs between two
 // MFMAs on the same accumulator instead of hipcc's back-to-back chains.
 #pragma once
@@ -21,6 +26,8 @@
 // IL: the DMA pieces of the next stage are issued BETWEEN the MFMA passes of the current one, predicated inside their asm statements
 // (no branch in the stage body: one basic block, so the address arithmetic of a piece is scheduled into the issue slots the
 // matrix pipe leaves free) instead of in two blocks of pieces behind uniform branches; the phase stamps are compiled out.
+// (no tail stages in the two shapes at the register limit: they would spill)
+#define WUNET_H3D_HAS_TAIL(M_REP_, NSEG_) ((M_REP_) < 4 && (NSEG_) < 16)
 template <int TAPS, int M_REP, int NSEG, bool BF = false, bool IL = false>
 __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A)
 {
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     for (int it = 0; it < WIT; ++it) {
         const int f = tid + it * WUNET_THREADS;
         const int which = f / (M_REP * WPM), r = f % (M_REP * WPM), mt = r / WPM, p = r % WPM;
-        woff[it] = ((mt * A.NCH * TAPS * 64 + p) * 8) | (which << 30);
+        woff[it] = ((mt * A.NS * TG * 64 + p) * 8) | (which << 30);
     }
     const wunet_lds_t xs_a = wunet_lds_addr(xs), ws_a = wunet_lds_addr(ws);
     const int wave_u = wunet_uniform(wave);
@@ -127,9 +134,9 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             else if ((m_live >> it) & 1) WUNET_H3D_X_PIECE(it, valid_, xh_, xl_)                                  \
         }                                                                                                         \
     }
-#define WUNET_H3D_ISSUE_W(MT0_, CH_, TG_)                                                                         \
+#define WUNET_H3D_ISSUE_W(MT0_, ST_)                                                                              \
     {                                                                                                             \
-        const long long boff_ = (long long)(((((size_t)(MT0_) * A.NCH + (CH_)) * TAPS + (TG_) * TG) * 64) * 16);  \
+        const long long boff_ = (long long)((((size_t)(MT0_) * A.NS + (ST_)) * TG * 64) * 16);                    \
         const long long wh_ = (long long)reinterpret_cast<size_t>(A.wh) + boff_, wl_ = (long long)reinterpret_cast<size_t>(A.wl) + boff_; \
         _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
             if ((it + 1) * WUNET_THREADS <= WP || tid + it * WUNET_THREADS < WP) {                                \
@@ -165,18 +172,22 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     int b = (tile * 256) >> A.logL, l0 = NSEG == 1 ? ((tile * 256) & (L - 1)) : 0, mt0 = mblk * M_REP;
     const bool split = gridDim.y > 1;
     const int st_beg = blockIdx.y * A.stages_per_split;
-    const int nstage = (st_beg + A.stages_per_split < A.NCH * NTG) ? st_beg + A.stages_per_split : A.NCH * NTG;
+    const int nstage = (st_beg + A.stages_per_split < A.NS) ? st_beg + A.stages_per_split : A.NS;
+    constexpr bool KT = WUNET_H3D_HAS_TAIL(M_REP, NSEG);
+    const int nfs = KT ? A.NFS : 0x7fffffff, tch = nfs / NTG;        // full stages (TG taps of a chunk of 4 channel groups); the tail stages' chunk
+    constexpr int NTT = (TAPS + 3) / 4;            // steps of a tail stage
     int stamp = 0;
     WUNET_H3D_STAMP(stamp) ++stamp;
     if (st_beg < nstage) {
-        WUNET_H3D_ISSUE_X(b, l0, st_beg / NTG)
-        WUNET_H3D_ISSUE_W(mt0, st_beg / NTG, st_beg % NTG)
+        WUNET_H3D_ISSUE_X(b, l0, (!KT || st_beg < nfs ? st_beg / NTG : tch))
+        WUNET_H3D_ISSUE_W(mt0, st_beg)
     }
 
     // this lane's 4 positions wave*64 + 4*i16 .. +3 lie in ONE batch item of the tile: item lseg, first sample ll0
     const int lpos = wave * 64 + i16 * 4;
     const int lseg = lpos / LSEG, ll0 = lpos - lseg * LSEG;
     const int boff = (q * COLS + ((lseg * SW + ll0) >> 2)) * 8;
+    const int boff_t = ((lseg * SW + ll0) >> 2) * 8;        // tail stages: + the group's plane
     const int aoff = (q * 16 + i16) * 8;
 
     for (;;) {
@@ -191,23 +202,30 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
         for (int st = st_beg; st < nstage; ++st) {
-            const int ch = st / NTG, tg = st - ch * NTG;
+            const bool tail = KT && st >= nfs;
+            const int ch = tail ? tch : st / NTG, tg = tail ? st - nfs : st - ch * NTG;     // (tail: tg = the group of its chunk)
             const bool last = st + 1 == nstage, has_next = !last || more;
-            const int nst = last ? st_beg : st + 1, nch = nst / NTG, ntg = nst - nch * NTG;
+            const int nst = last ? st_beg : st + 1, nch = (!KT || nst < nfs) ? nst / NTG : tch;
             const bool x_next = has_next && (last || nch != ch);
             wunet_setprio(0);
             wunet_wait_dma_barrier();             // this stage's x tile and W sub-tile have landed (every wave waited for its own pieces)
             WUNET_H3D_STAMP(stamp) ++stamp;
             wunet_setprio(3);
             // B fragments slide: with the interleaved column mapping fragment (n-tile nt, tap) is column 4*lane + nt + tap = F[nt + tap]
-            wunet_h8 fh[TG + 3], fl[TG + 3];
-#pragma unroll
-            for (int e = 0; e < TG + 3; ++e) {
-                const int ec = tg * TG + e + 8 - PAD;
-                const int po = ((ec & 3) * Q4 + (ec >> 2)) * 8;
-                fh[e] = wunet_ldh8(xs + boff + po);
-                if (!BF) fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
-            }
+            // (tail stage: every quarter reads the plane of the stage's group and its taps start at q * NTT; NTT + 3 fragments, the rest
+            // repeat the first).  ONE stage body for both kinds - a second copy of the MFMA block behind a branch cost 30 registers
+#define WUNET_H3D_LOAD_F(TAILS_)                                                                                  \
+    wunet_h8 fh[TG + 3], fl[TG + 3];                                                                              \
+    {                                                                                                             \
+        const int fb_ = ((TAILS_) && tail) ? boff_t + tg * COLS * 8 : boff;                                       \
+        const int e0_ = ((TAILS_) && tail) ? q * NTT : tg * TG;                                                   \
+        _Pragma("unroll") for (int e = 0; e < TG + 3; ++e) {                                                      \
+            const int ec = e0_ + ((TAILS_) && e >= NTT + 3 && tail ? 0 : e) + 8 - PAD;                            \
+            const int po = ((ec & 3) * Q4 + (ec >> 2)) * 8;                                                       \
+            fh[e] = wunet_ldh8(xs + fb_ + po);                                                                    \
+            if (!BF) fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + fb_ + po);                                            \
+        }                                                                                                         \
+    }
             wunet_h8 ah[2][M_REP], al[2][M_REP];
 #define WUNET_H3D_LOAD_A(BUF_, TL_)                                                                               \
     _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
@@ -222,15 +240,16 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             else if ((WHICH_) == 1) acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fl[(TL_) + nt], acc[mt][nt]);       \
             else acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);                          \
         }
-            WUNET_H3D_LOAD_A(0, 0)
             if (IL) {
+                WUNET_H3D_LOAD_F(false)
+                WUNET_H3D_LOAD_A(0, 0)
                 // ---- one basic block: pieces of the next x tile after passes 0 .. 9, of the next W sub-tile after passes 10 .. 14
                 constexpr int XPS = (XIT + 9) / 10, WPS = (WIT + 4) / 5;
                 const int xn = x_next ? 1 : 0, hn = has_next ? 1 : 0;
                 const int xb_ = last ? nb : b, xl0_ = last ? nl0 : l0, wmt0_ = last ? nmt0 : mt0;
                 const long long xoff_ = (long long)((((size_t)xb_ * A.C8 + nch * 4) * L + xl0_) * 16);
                 const long long xh_ = (long long)reinterpret_cast<size_t>(A.xh) + xoff_, xl_ = (long long)reinterpret_cast<size_t>(A.xl) + xoff_;
-                const long long woff_ = (long long)(((((size_t)wmt0_ * A.NCH + nch) * TAPS + ntg * TG) * 64) * 16);
+                const long long woff_ = (long long)((((size_t)wmt0_ * A.NS + nst) * TG * 64) * 16);
                 const long long wh_ = (long long)reinterpret_cast<size_t>(A.wh) + woff_, wl_ = (long long)reinterpret_cast<size_t>(A.wl) + woff_;
                 unsigned valid = m_live;
                 valid &= ~((NSEG > 1 || xl0_ == 0) ? m_lo : 0u);
@@ -285,31 +304,52 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
 #undef WUNET_H3D_SLOT
                 continue;
             }
+            // After the B fragments: the x tile is free once every wave holds them; the prefetch of the next step's A fragments is
+            // ISSUED at the fence, not sunk to its first use; with the last A fragments of the stage in flight the W sub-tile is free
+            // once every wave has them.  A tail stage runs the first NTT steps only.
+            WUNET_H3D_LOAD_F(true)
+            WUNET_H3D_LOAD_A(0, 0)
             if (x_next) {
-                wunet_wait_lds_barrier();         // every wave holds its B fragments: the x tile is free
+                wunet_wait_lds_barrier();
                 if (last) { WUNET_H3D_ISSUE_X(nb, nl0, nch) } else { WUNET_H3D_ISSUE_X(b, l0, nch) }
             }
-#pragma unroll
-            for (int tl = 0; tl < TG; ++tl) {
-                if (tl + 1 < TG) {
-                    if (tl & 1) { WUNET_H3D_LOAD_A(0, tl + 1) } else { WUNET_H3D_LOAD_A(1, tl + 1) }
-                }
-                wunet_sched_fence();              // the prefetch of the next tap's A fragments is ISSUED here, not sunk to its first use
-                if (tl & 1) { WUNET_H3D_PASS(0, 1, tl) } else { WUNET_H3D_PASS(0, 0, tl) }
-                if (tl == TG - 2) {
-                    // the last A fragments of this stage are in flight: once every wave has them the W sub-tile is free
-                    WUNET_H3D_STAMP(stamp)
-                    wunet_wait_lds_barrier();
-                    if (has_next) {
-                        if (last) { WUNET_H3D_ISSUE_W(nmt0, nch, ntg) } else { WUNET_H3D_ISSUE_W(mt0, nch, ntg) }
-                    }
-                }
-                if (tl & 1) { WUNET_H3D_PASS(1, 1, tl) WUNET_H3D_PASS(2, 1, tl) } else { WUNET_H3D_PASS(1, 0, tl) WUNET_H3D_PASS(2, 0, tl) }
+#define WUNET_H3D_RELEASE_W()                                                                                     \
+    {                                                                                                             \
+        WUNET_H3D_STAMP(stamp)                                                                                    \
+        wunet_wait_lds_barrier();                                                                                 \
+        if (has_next) {                                                                                           \
+            if (last) { WUNET_H3D_ISSUE_W(nmt0, nst) } else { WUNET_H3D_ISSUE_W(mt0, nst) }                       \
+        }                                                                                                         \
+    }
+#define WUNET_H3D_STEP(TL_)                                                                                       \
+    {                                                                                                             \
+        constexpr int tl = (TL_);                                                                                 \
+        if (tl + 1 < TG) {                                                                                        \
+            if (tl & 1) { WUNET_H3D_LOAD_A(0, tl + 1) } else { WUNET_H3D_LOAD_A(1, tl + 1) }                      \
+        }                                                                                                         \
+        wunet_sched_fence();                                                                                      \
+        if (tl & 1) { WUNET_H3D_PASS(0, 1, tl) } else { WUNET_H3D_PASS(0, 0, tl) }                                \
+        if (tl == TG - 2) WUNET_H3D_RELEASE_W()                                                                   \
+        else if (TG - 2 >= NTT && tl == NTT - 2) { if (tail) WUNET_H3D_RELEASE_W() }                              \
+        if (tl & 1) { WUNET_H3D_PASS(1, 1, tl) WUNET_H3D_PASS(2, 1, tl) } else { WUNET_H3D_PASS(1, 0, tl) WUNET_H3D_PASS(2, 0, tl) } \
+    }
+            // (the steps a tail stage skips behind ONE uniform branch; TG - 2 >= NTT, 5 taps: the W sub-tile of a full stage is
+            // released inside them, that of a tail stage at its step NTT - 2)
+            static_assert(TG == 5 && (NTT == 4 || NTT == 2), "step list below");
+            WUNET_H3D_STEP(0) WUNET_H3D_STEP(1)
+            if (NTT == 4) {
+                WUNET_H3D_STEP(2) WUNET_H3D_STEP(3)
+                if (!tail) { WUNET_H3D_STEP(4) }
+            } else if (!tail) {
+                WUNET_H3D_STEP(2) WUNET_H3D_STEP(3) WUNET_H3D_STEP(4)
             }
+#undef WUNET_H3D_STEP
+#undef WUNET_H3D_RELEASE_W
             ++stamp;
             WUNET_H3D_STAMP(stamp) ++stamp;
         }
 #undef WUNET_H3D_LOAD_A
+#undef WUNET_H3D_LOAD_F
 #undef WUNET_H3D_PASS
 
         // ---- epilogue (conv_h3_kernel's): un-scale, bias, store, BN statistics of the bias-free conv; a K split stores its
