@@ -155,7 +155,7 @@ def main():
                          "(configs[1], the enhancement.py path) - an extra measurement, same JSON shape")
     ap.add_argument("--torch-adam", action="store_true", help="use torch.optim.Adam instead of the fused HIP Adam (f1)")
     ap.add_argument("--gemm", choices=["split", "fp32", "bf16"], default=None,
-                    help="GEMM arithmetic of the levels >= 32 samples: split = 3 x f16 MFMA on hi/lo fp16 halves of every fp32 "
+                    help="GEMM arithmetic of the levels >= 16 samples: split = 3 x f16 MFMA on hi/lo fp16 halves of every fp32 "
                          "operand, fp32 accumulation (default, == WUNET_H3=1); fp32 = v_mfma_f32_16x16x4_f32 everywhere (WUNET_H3=0); "
                          "bf16 = bf16 operands, one MFMA pass (WUNET_H3=3; BASELINE configs[4], extra measurements only: outside "
                          "the 1e-4 fp32 parity bar)")
@@ -335,6 +335,11 @@ def main():
                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                         "traffic_whole_step": whole,
                         "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
+                        # the same kernel against the other roof: its algorithmic bytes / time, and where it sits relative to the ridge
+                        "algorithmic_GBps": top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9,
+                        "frac_of_hbm_peak": top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                        "intensity_flop_per_byte": top["flops"] / max(top["bytes"], 1.0),
+                        "ridge_flop_per_byte": peak * 1e12 / (PEAK_HBM_GBS * 1e9),
                         "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
                         "mfma_kernels_ms_per_step": mfma_ms,
                         "all_mfma_kernels_achieved": sum(r["flops"] for r in gemm_rows) / nprof / (mfma_ms * 1e-3) / 1e12,
@@ -385,8 +390,8 @@ def main():
                       if default_net else f"{args.frame}-sample frames/sec, {args.layers}-level Wave-U-Net, mode={args.mode} (extra)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("bf16 operands, f32 accumulate / BatchNorm / gradients (levels >= 32 samples: 1 x bf16 MFMA; the rest f32 MFMA)" if bf16_gemm
-                      else "f32 (levels >= 32 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
+            "dtype": ("bf16 operands, f32 accumulate / BatchNorm / gradients (levels >= 16 samples: 1 x bf16 MFMA; the rest f32 MFMA)" if bf16_gemm
+                      else "f32 (levels >= 16 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
                       else "f32"),
             "data": "synthetic",
             "config": {"workload": f"unet_basic {args.layers}-level, {args.frame}-sample frames, batch={args.batch} per GPU, fp32, "

@@ -47,11 +47,11 @@ const char* wunet_last_error(void);
 int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out);
 void wunet_destroy(wunet_ctx* ctx);
 
-/* GEMM arithmetic of the levels >= 32 samples.  enable = 1: forward convs, data gradients and weight
+/* GEMM arithmetic of the levels >= 16 samples.  enable = 1: forward convs, data gradients and weight
  * gradients run as fp16-split GEMMs - every fp32 operand x is carried as hi + lo in fp16 (22 significant bits; weights,
  * activations and gradients each with a power-of-two scale derived on the device, so the result does not depend on the
  * magnitude of the checkpoint), a product is three v_mfma_f32_16x16x32_f16 passes with fp32 accumulation -
- * wherever the position grid fills the chip (levels >= 256 samples; 128 .. 32 samples at >= 1024 positions per level,
+ * wherever the position grid fills the chip (levels >= 256 samples; 128 .. 16 samples at >= 1024 positions per level,
  * with split-K); 2: wherever the kernels can run (>= 16 samples; small test shapes); 0: fp32 MFMA
  * (v_mfma_f32_16x16x4_f32) everywhere.  Accuracy of the split path is at the fp32 noise floor, but the
  * arithmetic is not bit-identical to the fp32 path.  3 / 4: the layer sets of 1 / 2 in the bf16 mode of the same kernels -

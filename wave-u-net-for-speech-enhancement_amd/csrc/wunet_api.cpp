@@ -459,10 +459,12 @@ void layout_workspace(wunet_ctx* c)
             // the chip); forced (2): every level the kernels can run (tests of small shapes)
             l.first = (i == 0 && l.cin == 1 && l.taps == 15 && l.L >= 256) ? 1 : 0;
             // fp16-split kernels.  auto (1): levels >= 256 samples where the fp32 planner would launch an un-split
-            // full-width grid (enough 256-position tiles to fill the chip) and the 128- to 32-sample levels of a large
+            // full-width grid (enough 256-position tiles to fill the chip) and the 128- to 16-sample levels of a large
             // batch (split-K fills the chip there); forced (2): every level the kernels can run (tests of small shapes)
             const long long posn = (long long)B * l.L;
-            static const int min_l = getenv("WUNET_H3_MINL") ? atoi(getenv("WUNET_H3_MINL")) : 32;   // A/B switch; the 16-sample level measured slower on the split kernels (6.98 vs 6.94 ms)
+            // (A/B switch.  The 16-sample level was slower on the register-staged split kernels (6.98 vs 6.94 ms per step, min 32
+            // then); on conv_h3d_kernel<., ., 16> it is 20-38 us per step faster than on the fp32 kernels)
+            static const int min_l = getenv("WUNET_H3_MINL") ? atoi(getenv("WUNET_H3_MINL")) : 16;
             const bool big = c->h3 && !l.first && l.L >= 16 && posn >= 256 &&
                              (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : (l.L >= min_l && posn >= 1024)));
             l.h3f = big ? 1 : 0;
@@ -700,6 +702,19 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     return 0;
 }
 
+// wgrad_h3d_kernel (DMA-staged) runs this layer's weight gradient: whole chunks inside one item (L >= 128), both buffers within
+// the 160 KB
+size_t h3w_dma_smem(const LayerPlan& l, int bf)
+{
+    const int xg = l.taps == 15 ? 4 : 8, tp = l.h3w_tp, npl = bf ? 1 : 2;
+    return (size_t)2 * (npl * (l.h3w_mrep * 2) * (tp + 4) + npl * xg * (tp + 20) + 8) * 16;
+}
+bool h3w_is_dma(const LayerPlan& l, int bf)
+{
+    static const bool dma = getenv("WUNET_NO_H3W_DMA") == nullptr;                // A/B switch
+    const int tp = l.h3w_tp, nseg = l.L >= tp ? 1 : tp / l.L;
+    return dma && nseg == 1 && (tp == 128 || tp == 64) && h3w_dma_smem(l, bf) <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5);
+}
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
                     const float* sc, const float* sc2, const float* zero, float* part, int B, hipStream_t st, int bf = 0)
 {
@@ -707,13 +722,11 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
     const double posn = (double)B * l.L;
     const int xg = l.taps == 15 ? 4 : 8, tp = l.h3w_tp, nseg = l.L >= tp ? 1 : tp / l.L;
     const dim3 grid(l.h3w_ksplit, l.h3w_nblocks, l.h3w_mblocks);
-    // DMA-staged, double-buffered variant: whole chunks inside one item (L >= 128), both buffers within the 160 KB
     // (blocks of two m-tiles keep the register-staged kernel: it runs two blocks per CU, which is worth more)
-    static const bool dma = getenv("WUNET_NO_H3W_DMA") == nullptr;                // A/B switch
     const int npl = bf ? 1 : 2;
-    const size_t smem_d = (size_t)2 * (npl * (l.h3w_mrep * 2) * (tp + 4) + npl * xg * (tp + 20) + 8) * 16;
+    const size_t smem_d = h3w_dma_smem(l, bf);
     int rc;
-    if (dma && nseg == 1 && (tp == 128 || tp == 64) && smem_d <= 160 * 1024 && l.h3w_mrep <= (l.taps == 15 ? 6 : 5)) {
+    if (h3w_is_dma(l, bf)) {
         WgradH3dArgs a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;
         (void)zero;

@@ -25,7 +25,7 @@ class Engine:
     def __init__(self, lib=None, host_memory=False, h3=None):
         self.lib = lib if lib is not None else _lib.load_hip()
         self.host_memory = host_memory
-        # GEMM arithmetic of the levels >= 32 samples (include/wunet_hip.h: wunet_set_h3): 1 = fp16-split MFMA where the grid
+        # GEMM arithmetic of the levels >= 16 samples (include/wunet_hip.h: wunet_set_h3): 1 = fp16-split MFMA where the grid
         # fills the chip (default), 0 = fp32 MFMA everywhere (WUNET_H3=0), 2 = fp16-split wherever it can run (tests),
         # 3 = bf16 operands, one MFMA pass, on the planner's layers (BASELINE configs[4]), 4 = bf16 wherever it can run (tests)
         self.h3 = int(os.environ.get("WUNET_H3", "1")) if h3 is None else int(h3)
