@@ -1246,6 +1246,9 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL; p.Lt = l.Lt;
         const dim3 ga(l.cout, l.a_split);
         const bool tiny = l.L < 4;
+        // the first layer's g_z has one reader: its weight gradient forms it while it stages its chunks (WUNET_NO_GZ_FUSE: A/B switch)
+        const bool gz_in_wgrad = i == 0 && !tiny && !l.h3d && !l.h3w && l.w.wsplit && !getenv("WUNET_NO_GZ_FUSE") &&
+                                 !(l.a_split == 1 && (size_t)c->B * l.L <= 4 * WUNET_THREADS);       // (not where pass A finishes g_z itself)
         // a whole channel in one pass of one block (the levels of <= 16 samples at batch 64): BatchNorm-backward finalize and
         // g_z inside pass A - two launches of ~5 us (latency, not bandwidth) less per such level
         const bool fuse = !tiny && i < NL - 1 && !(i > 0 && l.h3d) && l.a_split == 1 && (size_t)c->B * l.L <= 4 * WUNET_THREADS &&
@@ -1314,7 +1317,8 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),
                                  (const float*)(ws + l.z), (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL,
                                  (size_t)c->B * l.cout * l.L, ws + l.g);
-                else
+                else if (gz_in_wgrad) {
+                } else
                     WUNET_LAUNCH(gz_materialize_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                  (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), l.cout, l.logL, n4, ws + l.g, l.Lt);   // in place
                 WUNET_CHECK_LAUNCH();
@@ -1341,7 +1345,10 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                          ws + c->h3_slot + 8 + 4 * i, ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i, ws + c->h3_slot,
                                          ws + c->wgpart_off, c->B, sd, c->bf);
                 else {
-                    const WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
+                    WgradArgs w = make_wgrad_args(xin, ws + l.g, ws + c->wgpart_off, c->B, l.cin, l.cout, l.L, l.taps, l.w.cps);
+                    if (gz_in_wgrad) {
+                        w.z = ws + l.z; w.k1 = ws + l.k1; w.k2 = ws + l.k2; w.k3 = ws + l.k3; w.Lt = l.Lt;
+                    }
                     rc = launch_wgrad_any(l.taps, w, l.w, sd);
                 }
                 if (rc) return rc;

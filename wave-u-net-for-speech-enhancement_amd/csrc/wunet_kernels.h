@@ -208,6 +208,10 @@ struct WgradArgs {
     int r4;                       // float4 per staged x row = nseg*segw/4
     int sw4;                      // float4 per segment = segw/4
     unsigned r4_magic, sw4_magic; // ceil(2^20 / r4), ceil(2^20 / sw4)
+    // WSPLIT (the first layer, Cin = 1: nothing else reads its g_z) with z != nullptr: g holds the gradient at the BatchNorm input's
+    // activation and the kernel forms g_z = k1[c] g + k2[c] z + k3[c] (zero in the row padding l >= Lt) while it stages the chunk -
+    // gz_materialize_kernel's pass (100 MB written and read back at the end of the backward's critical path) is not run
+    const float* z; const float* k1; const float* k2; const float* k3; int Lt;
 };
 
 template <int TAPS, int M_REP, int NW, int XIT, bool WSPLIT>
@@ -264,6 +268,20 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
         for (int k = 0; k < NW; ++k) acc[mt][k] = wunet_f4{0.f, 0.f, 0.f, 0.f};
 
     wunet_f4 greg[M_REP], xreg[XIT];
+    const bool fuse_gz = WSPLIT && A.z != nullptr;
+    wunet_f4 zreg[WSPLIT ? M_REP : 1];
+    float k1v[WSPLIT ? M_REP : 1], k2v[WSPLIT ? M_REP : 1], k3v[WSPLIT ? M_REP : 1];
+    if (WSPLIT) {
+#pragma unroll
+        for (int it = 0; it < M_REP; ++it) {
+            const int co_ = co0 + (tid >> 4) + 16 * it;
+            const bool ok_ = fuse_gz && co_ < A.Cout;
+            k1v[it] = ok_ ? A.k1[co_] : 1.0f;
+            k2v[it] = ok_ ? A.k2[co_] : 0.0f;
+            k3v[it] = ok_ ? A.k3[co_] : 0.0f;
+            zreg[it] = wunet_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 #define WUNET_WG_PREFETCH(P0_)                                                                                   \
     {                                                                                                            \
         const int p_ = (P0_) + 4 * gq;                                                                           \
@@ -273,6 +291,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
             const bool ok_ = b_ < A.B && co_ < A.Cout;                                                           \
             const size_t o_ = ok_ ? ((size_t)b_ * A.Cout + co_) * L + l_ : 0;                                    \
             greg[it] = wunet_ld4(A.g + o_);                                                                      \
+            if (WSPLIT) { if (fuse_gz) zreg[it] = wunet_ld4(A.z + o_); }                                         \
         }                                                                                                        \
         _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                     \
             const int gp_ = (P0_) + (xsg[it] << A.seg_shift);                                                    \
@@ -296,7 +315,18 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_mfma_kernel(WgradArgs A)
             const int b_ = p_ >> A.logL;
 #pragma unroll
             for (int it = 0; it < M_REP; ++it) {
-                const wunet_f4 gv = wunet_sel4(b_ < A.B && co0 + (tid >> 4) + 16 * it < A.Cout, greg[it]);
+                wunet_f4 gv = wunet_sel4(b_ < A.B && co0 + (tid >> 4) + 16 * it < A.Cout, greg[it]);
+                if (WSPLIT) {
+                    if (fuse_gz) {
+                        const int l_ = p_ & (L - 1);
+                        const wunet_f4 zv = wunet_sel4(b_ < A.B && co0 + (tid >> 4) + 16 * it < A.Cout, zreg[it]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = k1v[it] * gv[j] + k2v[it] * zv[j] + k3v[it];
+                            gv[j] = l_ + j < A.Lt ? v : 0.0f;
+                        }
+                    }
+                }
                 float* dst = gs + ((tid >> 4) + 16 * it) * GROW + 4 * gq;      // 8-byte aligned
                 reinterpret_cast<float2*>(dst)[0] = float2{gv[0], gv[1]};
                 reinterpret_cast<float2*>(dst)[1] = float2{gv[2], gv[3]};
