@@ -308,7 +308,7 @@ struct wunet_ctx {
     // lazily under the lock and never replaced, so replicas of one shape on several devices (or threads) do not disturb each other.
     // Everything else in the ctx is immutable after wunet_create / wunet_set_h3.
     struct Side {
-        hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pack = nullptr, ev_fpack = nullptr, ev_fpack2 = nullptr;
         const void* packed_ws = nullptr;      // the workspace whose backward weight packs the last training forward enqueued on `stream`
     };
     std::map<int, Side> side;
@@ -813,7 +813,9 @@ wunet_ctx::Side* side_for_current_device(wunet_ctx* c)
     if (hipStreamCreateWithFlags(&sd.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&sd.ev_fork, evf) != hipSuccess ||
         hipEventCreateWithFlags(&sd.ev_join, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&sd.ev_pack, evf) != hipSuccess) {
+        hipEventCreateWithFlags(&sd.ev_pack, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ev_fpack, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&sd.ev_fpack2, evf) != hipSuccess) {
         fail(WUNET_E_RUNTIME, "cannot create the side stream of device %d", dev);
         return nullptr;
     }
@@ -883,6 +885,7 @@ void wunet_destroy(wunet_ctx* ctx)
     if (!ctx) return;
     for (auto& kv : ctx->side) {
         hipStreamDestroy(kv.second.stream); hipEventDestroy(kv.second.ev_fork); hipEventDestroy(kv.second.ev_join); hipEventDestroy(kv.second.ev_pack);
+        hipEventDestroy(kv.second.ev_fpack); hipEventDestroy(kv.second.ev_fpack2);
     }
     delete ctx;
 }
@@ -925,8 +928,20 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         noisy = ws + c->pad_in;
         enhanced = ws + c->pad_out;
     }
-    // 1. pack all forward weights into MFMA-fragment order (one launch)
-    {
+    // 1. pack all forward weights into MFMA-fragment order (one launch each for the fp32 and the split packs).  A training forward
+    // whose first layer runs conv_first_kernel (it reads the raw weights) enqueues them - and the operand scales - on the side stream:
+    // conv_first and its BatchNorm finalize run beside them instead of behind three launches that only read the weights
+    // (WUNET_NO_EARLY_FPACK=1: A/B switch).  Order on the side stream: scales, split pack (first needed by layer 1), fp32 pack (the
+    // levels of <= 8 samples), then the backward's packs.
+    wunet_ctx::Side* fside = nullptr;
+    if (training && c->NL > 1 && c->ly[0].first && !g_prof_on) {
+        static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr || getenv("WUNET_NO_EARLY_FPACK") != nullptr;
+        if (!no_side) fside = side_for_current_device(c);
+        if (fside && (hipEventRecord(fside->ev_fork, st) != hipSuccess || hipStreamWaitEvent(fside->stream, fside->ev_fork, 0) != hipSuccess))
+            return fail(WUNET_E_RUNTIME, "fork onto the side stream failed");
+    }
+    const hipStream_t pst = fside ? fside->stream : st;
+    auto pack_fp32 = [&]() -> int {
         PackTable tab{};
         int nd = 0;
         for (int i = 0; i < c->NL; ++i) {
@@ -937,10 +952,12 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.M = l.cout; d.CP = l.f.cp; d.mtiles = l.f.mtiles_p; d.transposed = 0;
         }
         if (nd > 0) {
-            WUNET_LAUNCH(pack_weights_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_LAUNCH(pack_weights_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, pst, tab);
             WUNET_CHECK_LAUNCH();
         }
-    }
+        return 0;
+    };
+    if (!fside) { const int rc = pack_fp32(); if (rc) return rc; }
     if (c->h3) {
         // power-of-two scales of the split operands (wunet_h3_elem.h): partial max |W| of every layer with a split pack, and
         // the activation bounds the x scales derive from (training: from gamma / beta; eval: cleared here, measured per layer)
@@ -957,7 +974,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             }
             T.wmax = ws + c->wmax_off; T.slots = ws + c->fslot_off; T.training = training ? 1 : 0;
             if (any) {
-                WUNET_LAUNCH(h3_scales_kernel, dim3(WUNET_WMAX_PARTS, c->NL), dim3(WUNET_THREADS), 0, st, T);
+                WUNET_LAUNCH(h3_scales_kernel, dim3(WUNET_WMAX_PARTS, c->NL), dim3(WUNET_THREADS), 0, pst, T);
                 WUNET_CHECK_LAUNCH();
             }
         }
@@ -976,10 +993,17 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             d.bf = c->bf;
         }
         if (nd > 0) {
-            WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, st, tab);
+            WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, pst, tab);
             WUNET_CHECK_LAUNCH();
         }
     }
+    if (fside) {
+        if (hipEventRecord(fside->ev_fpack, pst) != hipSuccess) return fail(WUNET_E_RUNTIME, "recording the pack event failed");
+        const int rc = pack_fp32();
+        if (rc) return rc;
+        if (hipEventRecord(fside->ev_fpack2, pst) != hipSuccess) return fail(WUNET_E_RUNTIME, "recording the pack event failed");
+    }
+    bool fpack_joined = fside == nullptr, fpack2_joined = fside == nullptr;
     // The backward's flipped / transposed weight packs only depend on the weights (and on the maxima h3_scales_kernel has just
     // taken): a training forward that will be followed by a backward enqueues them on the side stream now, beside the first convs,
     // instead of leaving two launches at the head of the backward's critical path (WUNET_NO_EARLY_BPACK=1: A/B switch).
@@ -987,7 +1011,8 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         static const bool no_side = getenv("WUNET_NO_SIDE_STREAM") != nullptr || getenv("WUNET_NO_EARLY_BPACK") != nullptr;
         wunet_ctx::Side* side = (no_side || g_prof_on) ? nullptr : side_for_current_device(c);
         if (side) {
-            if (hipEventRecord(side->ev_fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->ev_fork, 0) != hipSuccess)
+            // (behind the forward's packs on the side stream when they are there: no second fork)
+            if (side != fside && (hipEventRecord(side->ev_fork, st) != hipSuccess || hipStreamWaitEvent(side->stream, side->ev_fork, 0) != hipSuccess))
                 return fail(WUNET_E_RUNTIME, "fork onto the side stream failed");
             const int rc = launch_backward_packs(c, params, ws, side->stream);
             if (rc) return rc;
@@ -997,6 +1022,16 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     }
     for (int i = 0; i < c->NL; ++i) {
         const LayerPlan& l = c->ly[i];
+        // (packs on the side stream: the operand scales and the split pack are first read by layer 1, the fp32 pack by the first
+        // layer on the fp32 kernels)
+        if (!fpack_joined && i >= 1) {
+            if (hipStreamWaitEvent(st, fside->ev_fpack, 0) != hipSuccess) return fail(WUNET_E_RUNTIME, "waiting for the weight packs failed");
+            fpack_joined = true;
+        }
+        if (!fpack2_joined && i >= 1 && !l.h3f) {
+            if (hipStreamWaitEvent(st, fside->ev_fpack2, 0) != hipSuccess) return fail(WUNET_E_RUNTIME, "waiting for the weight packs failed");
+            fpack2_joined = true;
+        }
         // 2a. materialise the conv input: BN scale/shift + LeakyReLU + decimation, or + x2 upsample + skip concat
         const float* xin = noisy;
         if (i > 0) {
@@ -1165,6 +1200,8 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_CHECK_LAUNCH();
         }
     }
+    if (!fpack_joined && hipStreamWaitEvent(st, fside->ev_fpack, 0) != hipSuccess) return fail(WUNET_E_RUNTIME, "waiting for the weight packs failed");
+    if (!fpack2_joined && hipStreamWaitEvent(st, fside->ev_fpack2, 0) != hipSuccess) return fail(WUNET_E_RUNTIME, "waiting for the weight packs failed");
     // 3. head
     {
         const LayerPlan& l = c->ly[c->NL - 1];
