@@ -231,6 +231,16 @@ inline float wunet_shfl_xor(float v, int mask)
     return blk.wave_a[wave][par][lane ^ mask];
 }
 
+inline double wunet_shfl_xor_d(double v, int mask)
+{
+    float h[2];
+    std::memcpy(h, &v, 8);
+    h[0] = wunet_shfl_xor(h[0], mask);
+    h[1] = wunet_shfl_xor(h[1], mask);
+    std::memcpy(&v, h, 8);
+    return v;
+}
+
 inline float wunet_row16_sum(float v)
 {
     for (int m = 1; m < 16; m <<= 1) v += wunet_shfl_xor(v, m);

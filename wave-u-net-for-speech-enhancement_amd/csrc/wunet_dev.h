@@ -20,6 +20,7 @@ __device__ __forceinline__ wunet_f4 wunet_mfma16(float a, float b, wunet_f4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float wunet_shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ double wunet_shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
 // sum of v over the 16 lanes of a row (lanes 16k .. 16k+15), in every lane, by DPP moves (no LDS crossbar, no lgkmcnt wait):
 // lane ^ 1, lane ^ 2 inside a quad, then the mirrored lane of the 8-group and of the row - after the quad steps all lanes of a
 // quad hold one value and after the third all lanes of an 8-group, so the mirrored partner holds exactly what lane ^ 4 / lane ^ 8

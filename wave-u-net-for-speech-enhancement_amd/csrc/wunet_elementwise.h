@@ -43,22 +43,25 @@ __global__ __launch_bounds__(WUNET_THREADS) void pack_weights_kernel(PackTable t
 }
 
 // ---------------------------------------------------------------------------- block reduce helper
-// sums two doubles over the 256-thread block; result valid in thread 0. red = 2*WUNET_THREADS doubles of LDS.
+// sums two doubles over the 256-thread block; result valid in thread 0. red = 2*WUNET_THREADS doubles of LDS (8 used).
+// Butterfly inside each wave (no barrier), the four wave sums through LDS: two barriers instead of the nine of a 256-wide LDS tree -
+// these reductions end kernels that are a few microseconds of pure latency (BatchNorm finalizes, split-K sums).  Fixed order.
 __device__ __forceinline__ void block_sum2(double& a, double& b, double* red)
 {
     const int tid = threadIdx.x;
-    red[tid] = a;
-    red[WUNET_THREADS + tid] = b;
-    __syncthreads();
-    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            red[tid] += red[tid + s];
-            red[WUNET_THREADS + tid] += red[WUNET_THREADS + tid + s];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        a += wunet_shfl_xor_d(a, m);
+        b += wunet_shfl_xor_d(b, m);
     }
-    a = red[0];
-    b = red[WUNET_THREADS];
+    __syncthreads();                           // (the previous user of red is done with it)
+    if ((tid & 63) == 0) {
+        red[tid >> 6] = a;
+        red[WUNET_WAVES + (tid >> 6)] = b;
+    }
+    __syncthreads();
+    a = (red[0] + red[1]) + (red[2] + red[3]);
+    b = (red[WUNET_WAVES] + red[WUNET_WAVES + 1]) + (red[WUNET_WAVES + 2] + red[WUNET_WAVES + 3]);
 }
 
 // max of two non-negative floats over the block (same LDS buffer, after a block_sum2); result valid in thread 0
@@ -66,19 +69,19 @@ __device__ __forceinline__ void block_max2(float& a, float& b, double* red)
 {
     float* fr = reinterpret_cast<float*>(red);
     const int tid = threadIdx.x;
-    __syncthreads();
-    fr[tid] = a;
-    fr[WUNET_THREADS + tid] = b;
-    __syncthreads();
-    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
-        if (tid < s) {
-            fr[tid] = fmaxf(fr[tid], fr[tid + s]);
-            fr[WUNET_THREADS + tid] = fmaxf(fr[WUNET_THREADS + tid], fr[WUNET_THREADS + tid + s]);
-        }
-        __syncthreads();
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        a = fmaxf(a, wunet_shfl_xor(a, m));
+        b = fmaxf(b, wunet_shfl_xor(b, m));
     }
-    a = fr[0];
-    b = fr[WUNET_THREADS];
+    __syncthreads();
+    if ((tid & 63) == 0) {
+        fr[tid >> 6] = a;
+        fr[WUNET_WAVES + (tid >> 6)] = b;
+    }
+    __syncthreads();
+    a = fmaxf(fmaxf(fr[0], fr[1]), fmaxf(fr[2], fr[3]));
+    b = fmaxf(fmaxf(fr[WUNET_WAVES], fr[WUNET_WAVES + 1]), fmaxf(fr[WUNET_WAVES + 2], fr[WUNET_WAVES + 3]));
 }
 
 // ---------------------------------------------------------------------------- BN forward finalize
