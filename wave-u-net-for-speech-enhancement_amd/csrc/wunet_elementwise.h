@@ -144,7 +144,17 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArg
     }
     double s1 = 0.0, s2 = 0.0;
     const float2* st = reinterpret_cast<const float2*>(A.stats) + (size_t)c * A.rows;     // [C][rows][2]
-    for (int r = tid; r < A.rows; r += WUNET_THREADS) {
+    // (four loads in flight: a plain loop over the run-time row count waits for every load - up to 16 serialised round trips on
+    // the long levels, whose tiles write 4096 rows per channel; same order of additions)
+    int r = tid;
+    for (; r + 3 * WUNET_THREADS < A.rows; r += 4 * WUNET_THREADS) {
+        const float2 v0 = st[r], v1 = st[r + WUNET_THREADS], v2 = st[r + 2 * WUNET_THREADS], v3 = st[r + 3 * WUNET_THREADS];
+        s1 += (double)v0.x; s2 += (double)v0.y;
+        s1 += (double)v1.x; s2 += (double)v1.y;
+        s1 += (double)v2.x; s2 += (double)v2.y;
+        s1 += (double)v3.x; s2 += (double)v3.y;
+    }
+    for (; r < A.rows; r += WUNET_THREADS) {
         const float2 v = st[r];
         s1 += (double)v.x;
         s2 += (double)v.y;
