@@ -1,13 +1,16 @@
 """Copies the summaries of a tools/measure_round.sh run (gpurun_out/final) into profiles/ under a tag and rebuilds
-profiles/pmc_traffic.json.  Usage: python tools/collect_round.py r2"""
+profiles/pmc_traffic.json.  Usage: python tools/collect_round.py r2          (here, after the gpurun call)
+                                   python tools/collect_round.py r2 --pmc-only   (on the GPU box, by measure_round.sh: only the stamped
+                                   PMC file, so that the bench runs that follow on the same box carry roofline.traffic)"""
 import csv, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench
 
 tag = sys.argv[1]
+pmc_only = "--pmc-only" in sys.argv[2:]
 F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
-for src, dst in (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_bf16.json"), ("bench_deep16_bf16.json", "bench_deep16_bf16.json"),
+for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_bf16.json"), ("bench_deep16_bf16.json", "bench_deep16_bf16.json"),
                  ("bench_deep16_split.json", "bench_deep16_split.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
@@ -51,6 +54,8 @@ out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE 
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(P, "pmc_traffic.json"), os.path.join(P, f"{tag}_pmc_traffic.json"))
 print("whole step HBM bytes %.3f GB" % (whole / 1e9))
+if pmc_only:
+    sys.exit(0)
 for name in ("bench.json", "bench_gemm_bf16.json", "bench_deep16_bf16.json", "bench_deep16_split.json", "serial_bench.json", "forward_bench.json"):
     pth = os.path.join(P, f"{tag}_{name}")
     if not os.path.exists(pth):
