@@ -142,6 +142,10 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
                                            ("WUNET_NO_PASSA_FUSE", 0, (4, 12, 5, 128)),   # separate BN-backward finalize + g_z
                                            ("WUNET_NO_GZ_FUSE", 2, (2, 24, 3, 1536)),     # first layer: g_z materialised instead of formed by its weight gradient (padded rows)
                                            ("WUNET_NO_GZ_FUSE", 0, (3, 8, 2, 2048)),
+                                           # split_sum_kernel launches between an encoder-side split-K data gradient and the pass A that reads it
+                                           ("WUNET_NO_SPLITSUM_FUSE", 2, (4, 16, 5, 1024)),
+                                           ("WUNET_NO_SPLITSUM_FUSE", 2, (3, 16, 3, 768)),
+                                           ("WUNET_NO_SPLITSUM_FUSE", 0, (5, 12, 3, 512)),
                                            ("WUNET_H3_PAIR WUNET_H3_KTAIL=0", 2, (2, 24, 2, 1024)),        # conv_h3p_kernel: two tiles per block, shared double-buffered W
                                            # conv_h3_kernel (register-staged x tile) instead of conv_h3d_kernel (DMA-staged, persistent;
                                            # its K tail - another order of the sums - off for both runs):

@@ -1225,6 +1225,17 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
 }  // extern "C"
 
 namespace {
+// dx of an encoder-side layer i (1 <= i <= n: encoder 1 .. middle) has ONE reader, pass A of layer i - 1, the next kernel on the
+// stream: a split-K data gradient leaves its partials in the scratch and that pass adds them itself, in split order (same bits), instead
+// of a split_sum_kernel launch in between.  (A decoder layer's dx is read again much later - its skip half by the encoder side - and is
+// summed as before.)  WUNET_NO_SPLITSUM_FUSE=1: A/B switch
+bool dx_stays_split(const wunet_ctx* c, int i)
+{
+    if (i < 1 || i > c->n || getenv("WUNET_NO_SPLITSUM_FUSE")) return false;
+    const LayerPlan& l = c->ly[i];
+    return l.d.ksplit > 1 && l.L >= 4 && c->ly[i - 1].L >= 4;       // (neither end on the scalar kernels of the 1-2-sample levels)
+}
+
 int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* params, const float* enhanced,
                         const float* grad_enhanced, void* workspace, float* const* grads,
                         int layer_begin, int layer_end, void* stream, bool join)
@@ -1319,6 +1330,9 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             const LayerPlan& dc = c->ly[2 * n - i];
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + dc.dx; p.Cg0 = dc.cin; p.coff = dc.c0; p.g1 = ws + nx.dx;
+            if (dx_stays_split(c, i + 1)) {
+                p.g1 = ws + c->spart_off; p.g1_splits = nx.d.ksplit; p.g1_stride = (size_t)c->B * nx.cin * nx.L;
+            }
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_ENC, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
@@ -1439,7 +1453,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                     nullptr, c->bf, l.h3d_ntt);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
-            if (split) {
+            if (split && !dx_stays_split(c, i)) {
                 const size_t nd = (size_t)c->B * l.cin * l.L;
                 size_t blocks = (nd + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (blocks > 2048) blocks = 2048;
@@ -1459,7 +1473,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             int rc = launch_conv(l.taps, "dgrad", a, l.d, st);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
-            if (split) {
+            if (split && !dx_stays_split(c, i)) {
                 size_t blocks = (nd + WUNET_THREADS - 1) / WUNET_THREADS;
                 if (blocks > 2048) blocks = 2048;
                 WUNET_LAUNCH(split_sum_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, (const float*)(ws + c->spart_off), l.d.ksplit, nd, ws + l.dx, (const float*)nullptr, 1, 0);

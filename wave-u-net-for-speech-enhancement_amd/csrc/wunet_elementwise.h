@@ -356,6 +356,8 @@ struct PassAArgs {
     const float* g0;     // HEAD: gh [B][L];  UP: dX [B][Cg0][2L];  ENC: dXdec [B][Cg0][L]
     const float* g1;     // HEAD: wh;         ENC: dXenc [B][C][L/2]
     int Cg0;             // channel count of the g0 tensor
+    int g1_splits;       // ENC: > 1 - g1 points at the split-K partials of the data gradient (g1_stride floats apart): this pass is their
+    size_t g1_stride;    //      only reader and adds them itself, in split order, instead of a split_sum_kernel launch in front of it
     int coff;            // ENC: channel offset of the skip part inside dXdec
     int B, C, L, logL;
     float up_scale;      // UP: (float)(Lt-1)/(2Lt-1)
@@ -399,7 +401,24 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         } else if (MODE == A_ENC) {
             const wunet_f4 gd = wunet_ld4(A.g0 + ((size_t)b * A.Cg0 + A.coff + c) * A.L + l);
             const float* ge = A.g1 + ((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1);
-            g[0] = gd[0] + ge[0]; g[1] = gd[1]; g[2] = gd[2] + ge[1]; g[3] = gd[3];
+            float e0, e1;
+            if (A.g1_splits > 1) {                            // (four loads in flight, the order of split_sum_kernel's additions)
+                e0 = e1 = 0.0f;
+                int k = 0;
+                for (; k + 4 <= A.g1_splits; k += 4) {
+                    const float2 t0 = *reinterpret_cast<const float2*>(ge + (size_t)k * A.g1_stride);
+                    const float2 t1 = *reinterpret_cast<const float2*>(ge + (size_t)(k + 1) * A.g1_stride);
+                    const float2 t2 = *reinterpret_cast<const float2*>(ge + (size_t)(k + 2) * A.g1_stride);
+                    const float2 t3 = *reinterpret_cast<const float2*>(ge + (size_t)(k + 3) * A.g1_stride);
+                    e0 += t0.x; e0 += t1.x; e0 += t2.x; e0 += t3.x;
+                    e1 += t0.y; e1 += t1.y; e1 += t2.y; e1 += t3.y;
+                }
+                for (; k < A.g1_splits; ++k) {
+                    const float2 t = *reinterpret_cast<const float2*>(ge + (size_t)k * A.g1_stride);
+                    e0 += t.x; e1 += t.y;
+                }
+            } else { e0 = ge[0]; e1 = ge[1]; }
+            g[0] = gd[0] + e0; g[1] = gd[1]; g[2] = gd[2] + e1; g[3] = gd[3];
         } else {
             // transpose of ATen's upsample_linear1d: output j contributes l0 to input i0(j) and l1 to i1(j), with the
             // fp32-computed coordinates; inputs l..l+3 can only be hit by outputs j in [2l-2, 2l+8], walked in
