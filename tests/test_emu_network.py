@@ -146,6 +146,9 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
                                            ("WUNET_NO_SPLITSUM_FUSE", 2, (4, 16, 5, 1024)),
                                            ("WUNET_NO_SPLITSUM_FUSE", 2, (3, 16, 3, 768)),
                                            ("WUNET_NO_SPLITSUM_FUSE", 0, (5, 12, 3, 512)),
+                                           # bn_finalize_bwd_kernel as a launch of its own in front of gz_split_h3_kernel instead of in its blocks' prologue
+                                           ("WUNET_NO_BWDFIN_FUSE", 2, (4, 16, 5, 1024)),
+                                           ("WUNET_NO_BWDFIN_FUSE", 2, (2, 24, 3, 1536)),
                                            ("WUNET_H3_PAIR WUNET_H3_KTAIL=0", 2, (2, 24, 2, 1024)),        # conv_h3p_kernel: two tiles per block, shared double-buffered W
                                            # conv_h3_kernel (register-staged x tile) instead of conv_h3d_kernel (DMA-staged, persistent;
                                            # its K tail - another order of the sums - off for both runs):

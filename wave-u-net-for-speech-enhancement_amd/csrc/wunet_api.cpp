@@ -1345,8 +1345,14 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
             b.C = l.cout; b.count = (double)c->B * l.Lt;
             b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
-            WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
-            WUNET_CHECK_LAUNCH();
+            // (short levels on the split kernels: the finalize runs in the prologue of gz_split_h3_kernel's blocks instead -
+            //  WUNET_NO_BWDFIN_FUSE=1: A/B switch)
+            static const int fin_loads = getenv("WUNET_GZ_FIN_LOADS") ? atoi(getenv("WUNET_GZ_FIN_LOADS")) : WUNET_GZ_FIN_LOADS;      // (sweep switch)
+            const bool fin_in_gz = i > 0 && l.h3d && l.a_split * l.cout <= fin_loads && l.cout <= WUNET_GZ_FIN_C && !getenv("WUNET_NO_BWDFIN_FUSE");
+            if (!fin_in_gz) {
+                WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
+                WUNET_CHECK_LAUNCH();
+            }
 
             // ---- g_z = k1*g + k2*z + k3, materialised once for both gradient GEMMs (fp32 in place, or scaled hi/lo halves)
             {
@@ -1359,10 +1365,16 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                     if (hb > 8192) hb = 8192;
                     prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * (8.0 + (c->bf ? 2.0 : 4.0)));
-                    WUNET_LAUNCH(gz_split_h3_kernel, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                                 (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
-                                 ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                 c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt);
+                    if (fin_in_gz)
+                        WUNET_LAUNCH(gz_split_h3_kernel<true>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                                     (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
+                                     ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
+                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b);
+                    else
+                        WUNET_LAUNCH(gz_split_h3_kernel<false>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
+                                     (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
+                                     ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
+                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b);
                     prof_end(st);
                 } else if (tiny)
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),

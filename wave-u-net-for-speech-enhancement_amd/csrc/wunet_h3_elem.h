@@ -236,13 +236,57 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3R
 // power-of-two scale comes from an upper bound of max |g_z| (bn_finalize_bwd_kernel's bound[c], max over channels) so
 // no pass over g_z is needed before writing it: 2^k * bound in [512, 1024).  Every block derives the same scale;
 // block 0 publishes {scale, 1/scale} for the GEMMs.  One thread per (channel group, 4 samples).
+// FIN (levels with at most WUNET_GZ_FIN_LOADS channels x partial rows of pass A, C <= WUNET_GZ_FIN_C): the BatchNorm-backward
+// finalize (bn_finalize_bwd_kernel: sums of the partial rows -> d gamma, d beta, k1..k3, the bound) runs in EVERY block's prologue - a
+// few hundred loads that hit the L2 - instead of in a launch of its own in front of this one: on those levels that launch is 4 us of
+// latency + a kernel boundary on the backward's critical path.  Block 0 publishes the results.  The sums run over the rows in order,
+// in double: the same numbers as the tree of the separate kernel to the last bit of the float results.
+#define WUNET_GZ_FIN_LOADS 1536   // (sweep 1152 / 2048 / 3100 / all: 5.41 / 5.42 / 5.46 / 5.50 ms per step - beyond the 512-sample level the prologue costs more than the launch)
+#define WUNET_GZ_FIN_C 512
+template <bool FIN>
 __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                      const float* k3, const float* bound, float* sc, wunet_half* hi,
-                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int bf, int Lt)
+                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int bf, int Lt,
+                                                                     BnBwdArgs F)
 {
     __shared__ float red[WUNET_THREADS];
+    __shared__ float ks[FIN ? 3 * WUNET_GZ_FIN_C : 3];
     float m = 0.0f;
-    for (int c = threadIdx.x; c < C; c += WUNET_THREADS) m = fmaxf(m, bound[c]);
+    if (FIN) {
+        for (int c = threadIdx.x; c < C; c += WUNET_THREADS) {
+            double s1 = 0.0, s2 = 0.0;
+            float mg = 0.0f, mz = 0.0f;
+            for (int r0 = 0; r0 < F.rows; r0 += 8) {
+                float p1[8], p2[8], q1[8], q2[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {                         // eight rows' loads first (clamped rows, selected below)
+                    const size_t o = ((size_t)(r0 + r < F.rows ? r0 + r : 0) * F.C + c) * 2;
+                    p1[r] = F.part[o]; p2[r] = F.part[o + 1];
+                    q1[r] = F.pmax[o]; q2[r] = F.pmax[o + 1];
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (r0 + r < F.rows) {
+                        s1 += (double)p1[r]; s2 += (double)p2[r];
+                        mg = fmaxf(mg, q1[r]); mz = fmaxf(mz, q2[r]);
+                    }
+                }
+            }
+            const double m1 = s1 / F.count, m2 = s2 / F.count;
+            const double a = (double)F.gamma[c] * (double)F.rstd[c];
+            const float k1c = (float)a, k2c = (float)(-a * m2 * (double)F.rstd[c]);
+            const float k3c = (float)(a * m2 * (double)F.rstd[c] * (double)F.mean[c] - a * m1);
+            const float bc = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)F.rstd[c]) * (double)mz + fabs(a * m1));
+            ks[c] = k1c; ks[WUNET_GZ_FIN_C + c] = k2c; ks[2 * WUNET_GZ_FIN_C + c] = k3c;
+            m = fmaxf(m, bc);
+            if (blockIdx.x == 0) {
+                F.dgamma[c] = (float)s2; F.dbeta[c] = (float)s1; F.dbias[c] = 0.0f;
+                F.k1[c] = k1c; F.k2[c] = k2c; F.k3[c] = k3c; F.bound[c] = bc;
+            }
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += WUNET_THREADS) m = fmaxf(m, bound[c]);
+    }
     red[threadIdx.x] = m;
     __syncthreads();
     for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
@@ -282,7 +326,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                 const bool ok = c < C;
                 const size_t o = ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4;
                 const wunet_f4 gv = wunet_ld4(g + o), zv = wunet_ld4(z + o);
-                const float a = k1[ok ? c : 0], bb = k2[ok ? c : 0], d = k3[ok ? c : 0];
+                const int cc = ok ? c : 0;
+                const float a = FIN ? ks[cc] : k1[cc], bb = FIN ? ks[WUNET_GZ_FIN_C + cc] : k2[cc], d = FIN ? ks[2 * WUNET_GZ_FIN_C + cc] : k3[cc];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[e][j] = (ok && 4 * l4 + j < Lt) ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;     // (row padding: no gradient)
             }
