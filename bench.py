@@ -135,7 +135,26 @@ def cpu_baseline(seconds_budget=20.0):
             best = (nt, ts[1])
         if time.perf_counter() - t_start > seconds_budget:
             break
-    return {"value": 4.0 / best[1], "unit": "frames/s", "cores": best[0], "kind": "port",
+    # side figures at the best thread count: eval-mode forward at batch 1 and 4 (BASELINE configs[1], the
+    # enhancement.py path), and one training step at the bench's batch 64 (configs[2])
+    torch.set_num_threads(best[0])
+    side = {}
+    with torch.no_grad():
+        sde = {k: v.detach() for k, v in sd.items()}
+        for b in (1, 4):
+            xb, _ = synthetic_batch(b, "cpu", 1)
+            torch_port.forward(sde, xb, N_LAYERS, CI, False)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                torch_port.forward(sde, xb, N_LAYERS, CI, False)
+                ts.append(time.perf_counter() - t0)
+            side[f"eval_forward_batch{b}_frames_per_s"] = b / sorted(ts)[1]
+    if time.perf_counter() - t_start < seconds_budget + 5.0:
+        noisy, clean = synthetic_batch(64, "cpu", 0)
+        one_step()
+        side["train_batch64_frames_per_s"] = 64.0 / one_step()
+    return {"value": 4.0 / best[1], "unit": "frames/s", "cores": best[0], "kind": "port", "side": side,
             "sample": f"batch=4 x {FRAME}-sample frames, fwd+smooth_l1+bwd+Adam, median of 3 steps at the best of "
                       f"{list(tried)} threads (torch {torch.__version__} CPU ATen kernels = the reference's "
                       "CUDA_VISIBLE_DEVICES=-1 path)",
