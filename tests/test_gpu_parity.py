@@ -496,6 +496,42 @@ def test_split_ops_at_baseline_geometries(engine, dev, prefix, Cin, Cout, K, L):
     check(dw, dwr, "wgrad")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("Cin,Cout,K,L", [(24, 48, 15, 8192),      # 3 left-over channel groups, no full chunk (encoder 1)
+                                          (72, 96, 15, 2048),      # 2 chunks + 1 group forward, 3 chunks backward (encoder 3)
+                                          (48, 72, 15, 4096),      # 1 chunk + 2 groups (encoder 2)
+                                          (72, 24, 5, 1024)])      # 5 taps: 2 chunks + one 2-step tail stage (the last decoder layer's channels)
+def test_k_tail_on_hardware(engine, dev, monkeypatch, Cin, Cout, K, L):
+    """conv_h3d_kernel's K tail (left-over channel groups as tail stages, the taps spread over the K quarters of the MFMA) against the
+    zero-padded last chunk (WUNET_H3_KTAIL=0, read when the op plans its tiling) on the hardware's MFMA: forward conv and data
+    gradient agree with float64 F.conv1d to 1e-5 either way, and the two are not the same numbers (the tail really ran)."""
+    import torch.nn.functional as F
+    B = 16
+    g = torch.Generator().manual_seed(L + Cin)
+    x = torch.randn(B, Cin, L, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / float(np.sqrt(Cin * K))
+    b = torch.randn(Cout, generator=g)
+    gz = torch.randn(B, Cout, L, generator=g)
+    xd, wd, bd, gd = x.to(dev), w.to(dev), b.to(dev), gz.to(dev)
+    lib = engine.lib
+    items = [0, B - 1]
+    zr = F.conv1d(x.double()[items], w.double(), b.double(), padding=K // 2)
+    dxr = torch.nn.grad.conv1d_input((len(items), Cin, L), w.double(), gz.double()[items], padding=K // 2)
+    got = {}
+    for kt in ("0", "1"):
+        monkeypatch.setenv("WUNET_H3_KTAIL", kt)
+        z = torch.full((B, Cout, L), float("nan"), device=dev)
+        dx = torch.full((B, Cin, L), float("nan"), device=dev)
+        assert lib.wunet_op_conv1d_split(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), z.data_ptr(), B, Cin, Cout, L, K, None) == 0, lib.wunet_last_error()
+        assert lib.wunet_op_conv1d_dgrad_split(gd.data_ptr(), wd.data_ptr(), dx.data_ptr(), B, Cin, Cout, L, K, None) == 0, lib.wunet_last_error()
+        torch.cuda.synchronize()
+        got[kt] = (z.cpu(), dx.cpu())
+        for t, ref, what in ((z[items], zr, "conv"), (dx[items], dxr, "dgrad")):
+            t = t.cpu().double()
+            assert ((t - ref).norm() / ref.norm()).item() < 1e-5 and ((t - ref).abs().max() / ref.abs().max()).item() < 1e-5, (kt, what)
+    assert not (torch.equal(got["0"][0], got["1"][0]) and torch.equal(got["0"][1], got["1"][1]))
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the split path must not depend on the gauge of the checkpoint (conv -> BatchNorm: model/unet_basic.py:9-14, 22-27)
 def _rescaled(n, ci, wscale=1.0, gscale=1.0):
