@@ -128,6 +128,15 @@ int wunet_num_conv_layers(const wunet_ctx* ctx);
 int wunet_profile_enable(int on);
 long long wunet_profile_collect(char* buf, size_t cap);
 
+/* SURVEY.md section 8 (f4), the data input path.  Replaces, for a whole batch and on the device, the reference's per-item aligned
+ * random crop - `sample_fixed_length_data_aligned(mixture, clean, sample_length)`, /root/reference/util/utils.py:101-113, called from
+ * `Dataset.__getitem__`, dataset/waveform_dataset.py:56-67 - and the collate of train.py:15-21: window b of BOTH outputs is
+ * samples starts[b] .. starts[b] + length - 1 of the two flat float32 arrays (`total` samples each, resident in HBM; starts = device
+ * int64, drawn by the caller with the reference's distribution: uniform over [item_start, item_start + item_length - length]).
+ * mixture / clean receive [batch][1][length] float32.  Starts outside [0, total - length] are clamped (never an out-of-range read). */
+int wunet_crop_windows(const float* mixture_flat, const float* clean_flat, const long long* starts, long long total,
+                       int batch, int length, float* mixture, float* clean, void* stream);
+
 /* Measurement aid (tools/conv_trace.py; no reference counterpart): a device buffer of gridDim.x * 64 uint64 that the DMA-staged
  * conv / data-gradient kernel (conv_h3d_kernel) fills with shader-clock stamps of each block's phases (entry; per K stage: tile
  * landed, W buffer released, MFMAs issued; epilogue done), or NULL (default) to turn the stamps off.  Process-wide. */

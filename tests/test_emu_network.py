@@ -122,7 +122,7 @@ def test_fp16_split_train_step_matches_oracle(emu_engine_h3, n, ci, B, T, loss):
 
 
 def test_fp16_split_four_rows_per_wave(emu_engine_h3, monkeypatch):
-    """conv_h3_kernel<TAPS, 4, 1> (64 output rows per block; the planner picks it for the large 5-tap layers of the
+    """conv_h3d_kernel<TAPS, 4, 1> (64 output rows per block; the planner picks it for the large 5-tap layers of the
     12-level net, too large for the emulator) forced through the A/B switches on a net whose m-tile counts are 4 and 8."""
     monkeypatch.setenv("WUNET_H3_ORDER", "432")
     monkeypatch.setenv("WUNET_H3D_ORDER", "432")
@@ -136,38 +136,20 @@ def test_fp16_split_serial_weight_gradient_reduce(emu_engine_h3, monkeypatch):
     test_fp16_split_train_step_matches_oracle(emu_engine_h3, 3, 16, 3, 1024, "mse")
 
 
-@pytest.mark.parametrize("switch,h3,cfg", [("WUNET_PREP4", 2, (4, 20, 3, 1024)),          # operand passes: 4 samples per thread
-                                           ("WUNET_NO_SKIP_FUSE", 2, (4, 16, 3, 1024)),   # decoder-side pass reads the skip itself
-                                           ("WUNET_NO_PASSA_FAST", 2, (4, 20, 3, 1024)),  # generic upsample-transpose walk
-                                           ("WUNET_NO_PASSA_FUSE", 0, (4, 12, 5, 128)),   # separate BN-backward finalize + g_z
-                                           ("WUNET_NO_GZ_FUSE", 2, (2, 24, 3, 1536)),     # first layer: g_z materialised instead of formed by its weight gradient (padded rows)
-                                           ("WUNET_NO_GZ_FUSE", 0, (3, 8, 2, 2048)),
-                                           # split_sum_kernel launches between an encoder-side split-K data gradient and the pass A that reads it
-                                           ("WUNET_NO_SPLITSUM_FUSE", 2, (4, 16, 5, 1024)),
-                                           ("WUNET_NO_SPLITSUM_FUSE", 2, (3, 16, 3, 768)),
-                                           ("WUNET_NO_SPLITSUM_FUSE", 0, (5, 12, 3, 512)),
-                                           # bn_finalize_bwd_kernel as a launch of its own in front of gz_split_h3_kernel instead of in its blocks' prologue
-                                           ("WUNET_NO_BWDFIN_FUSE", 2, (4, 16, 5, 1024)),
-                                           ("WUNET_NO_BWDFIN_FUSE", 2, (2, 24, 3, 1536)),
-                                           ("WUNET_H3_PAIR WUNET_H3_KTAIL=0", 2, (2, 24, 2, 1024)),        # conv_h3p_kernel: two tiles per block, shared double-buffered W
-                                           # conv_h3_kernel (register-staged x tile) instead of conv_h3d_kernel (DMA-staged, persistent;
-                                           # its K tail - another order of the sums - off for both runs):
-                                           # 8 blocks walk all work items, split-K stages
-                                           ("WUNET_H3_XDMA=0 WUNET_H3_KTAIL=0 WUNET_H3_GRID=8", 2, (2, 24, 2, 1024)),
+@pytest.mark.parametrize("switch,h3,cfg", [("WUNET_NO_SKIP_FUSE", 2, (4, 16, 3, 1024)),   # decoder-side pass reads the skip itself (eval mode's path) vs written by the encoder side
+                                           # conv_h3d_kernel: 8 persistent blocks walk all work items (the emulator's default grid is one item per block), split-K stages
+                                           ("WUNET_H3_GRID=8", 2, (2, 24, 2, 1024)),
                                            # ... un-split (bias + BatchNorm statistics in the epilogue), 64-row blocks, edge tiles of every item
-                                           ("WUNET_H3_XDMA=0 WUNET_H3_KTAIL=0 WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1 WUNET_H3_ORDER=432 WUNET_H3D_ORDER=432", 2, (2, 32, 3, 1024)),
+                                           ("WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1 WUNET_H3_ORDER=432 WUNET_H3D_ORDER=432", 2, (2, 32, 3, 1024)),
                                            # ... channel counts off the 8 / 32 grid (zero-page pieces in the last chunk), 16 blocks
-                                           ("WUNET_H3_XDMA=0 WUNET_H3_KTAIL=0 WUNET_H3_GRID=16 WUNET_H3_NOSPLIT=1", 2, (1, 20, 3, 2048)),
+                                           ("WUNET_H3_GRID=16 WUNET_H3_NOSPLIT=1", 2, (1, 20, 3, 2048)),
                                            # ... tiles of 2 .. 8 whole items (128 .. 32 samples), odd batch: items beyond the batch in the last tile
-                                           ("WUNET_H3_XDMA=0 WUNET_H3_KTAIL=0 WUNET_H3_GRID=8", 2, (6, 16, 5, 1024)),
-                                           ("WUNET_H3_XDMA=0 WUNET_H3_KTAIL=0 WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1", 2, (5, 12, 3, 1024)),
-                                           # conv_h3d_kernel with the DMA pieces issued between the MFMA passes (one basic block per stage)
-                                           ("WUNET_H3_IL=1 WUNET_H3_KTAIL=0 WUNET_H3_GRID=8", 2, (2, 24, 2, 1024)),
-                                           ("WUNET_H3_IL=1 WUNET_H3_KTAIL=0 WUNET_H3_GRID=16 WUNET_H3_NOSPLIT=1 WUNET_H3_ORDER=432 WUNET_H3D_ORDER=432", 2, (2, 40, 3, 1024))])
-def test_measurement_switches_are_bit_identical(switch, h3, cfg, monkeypatch):
-    """The fused / re-mapped kernels of the default path compute exactly what the forms they replaced compute:
-    one training step with and without the A/B switch gives the same output and the same gradients, bit for bit.
-    ("A=v B=w ...": A=v is the switch, the other settings hold for both runs.)"""
+                                           ("WUNET_H3_GRID=8", 2, (6, 16, 5, 1024)),
+                                           ("WUNET_H3_GRID=8 WUNET_H3_NOSPLIT=1", 2, (5, 12, 3, 1024))])
+def test_planner_hooks_are_bit_identical(switch, h3, cfg, monkeypatch):
+    """The result must not depend on how the work is dealt out: one training step with and without the hook (persistent blocks
+    walking many work items vs one item per block; the skip half written by either operand pass) gives the same output and the same
+    gradients, bit for bit.  ("A=v B=w ...": A=v is the hook, the other settings hold for both runs.)"""
     n, ci, B, T = cfg
     eng_mod = importlib.import_module(PKG_NAME + ".engine")
     lib_mod = importlib.import_module(PKG_NAME + "._lib")

@@ -181,3 +181,75 @@ def test_second_backward_and_input_gradient_are_refused_with_a_message(emu_engin
     with pytest.raises(NotImplementedError, match="waveform input"):
         m(x.clone().requires_grad_(True))
     assert torch.equal(m.encoder[0].main[1].num_batches_tracked, before)      # refused before the forward touched the buffers
+
+
+def test_fused_adam_load_state_dict_normalises_the_step(emu_engine):
+    """A resumed state must hold "step" the way FusedAdam keeps it - a float32 scalar on the host - whatever the checkpoint held:
+    the Python int of the torch 1.2 the reference was tested with (README.md:27), or a tensor that map_location moved elsewhere
+    (trainer._resume_checkpoint loads with map_location=device: a device-side step would cost one blocking read-back per
+    parameter per step and abort a graph capture)."""
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    torch.manual_seed(5)
+    base = [torch.randn(6, 4), torch.randn(3)]
+
+    def fresh(lr=1e-2):
+        ps = [torch.nn.Parameter(t.clone()) for t in base]
+        o = optim_mod.FusedAdam(ps, lr=lr)
+        o._engine_override = emu_engine
+        return ps, o
+
+    def grads(ps, k):
+        g = torch.Generator().manual_seed(20 + k)
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=g)
+
+    pa, fa = fresh()
+    for k in range(3):
+        grads(pa, k); fa.step()
+    for form in ("int", "f64-tensor", "f32-1d"):
+        sd = copy.deepcopy(fa.state_dict())
+        for st in sd["state"].values():
+            st["step"] = {"int": 3, "f64-tensor": torch.tensor(3.0, dtype=torch.float64), "f32-1d": torch.tensor([3.0])[0]}[form]
+        pb, fb = fresh()
+        fb.load_state_dict(sd)
+        with torch.no_grad():
+            for p, q in zip(pb, pa):
+                p.copy_(q)
+        for st in fb.state.values():
+            assert torch.is_tensor(st["step"]) and st["step"].device.type == "cpu" and st["step"].dtype == torch.float32
+            assert st["step"].dim() == 0 and float(st["step"]) == 3.0
+        pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        fc = optim_mod.FusedAdam(pc, lr=1e-2)
+        fc._engine_override = emu_engine
+        fc.load_state_dict(copy.deepcopy(fa.state_dict()))
+        grads(pb, 9); grads(pc, 9)
+        fb.step(); fc.step()
+        for b, c in zip(pb, pc):
+            assert torch.equal(b, c), form
+    # the signature a graph-replaying driver compares (trainer.Trainer._step re-captures when it changes)
+    sig = fa.hyper_signature()
+    fa.param_groups[0]["lr"] = 5e-3
+    assert fa.hyper_signature() != sig
+    sig = fa.hyper_signature()
+    fa.grad_scale = 0.5
+    assert fa.hyper_signature() != sig
+
+
+def test_engine_never_evicts_a_context_in_use(emu_engine):
+    """engine.Engine keeps at most MAX_CONTEXTS shapes, least recently used first - but never destroys a context some caller still
+    holds (stock nn.DataParallel drives one thread per replica through one engine, trainer/base_trainer.py:26-27)."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+    eng.MAX_CONTEXTS = 2
+    with eng._using(1, 4, 1, 8) as held:
+        handles = []
+        for b in (2, 3, 4, 5):
+            with eng._using(1, 4, b, 8) as h:
+                handles.append(h.value)
+        assert (1, 4, 1, 8, "None") in eng._ctx                       # still there: it is held
+        assert len(eng._ctx) <= 3
+        assert eng.lib.wunet_num_conv_layers(held) == 3                # and alive
+    with eng._using(1, 4, 6, 8):
+        pass
+    assert (1, 4, 1, 8, "None") not in eng._ctx and len(eng._ctx) <= 2  # released -> evictable

@@ -1,4 +1,4 @@
-"""world_size=2 gloo tests (CPU) of the data-parallel path: parallel.GradSync buckets the flat
+"""world_size 2 / 4 / 8 gloo tests (CPU) of the data-parallel path: parallel.GradSync buckets the flat
 gradient buffer in backward order, all-reduces each finished bucket and averages - and the result
 equals the average of the per-shard oracle gradients with per-shard BatchNorm (the DataParallel
 semantics of the reference, trainer/base_trainer.py:26-27)."""
@@ -84,26 +84,34 @@ def _worker(rank, world, port, tmpdir):
         dist.destroy_process_group()
 
 
-def test_grad_sync_matches_average_of_shard_oracles(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_grad_sync_matches_average_of_shard_oracles(tmp_path, world):
+    """with the global batch split into `world` equal shards (nn.DataParallel's scatter,
+    trainer/base_trainer.py:26-27), every rank ends the backward holding the MEAN of the per-shard oracle gradients - each shard
+    back-propagated on its own with its own BatchNorm statistics - at world 2, 4 and the node's 8."""
     from oracle import c_oracle, plan
-    world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     n, ci, B, T = 3, 8, 2, 64
     noisy, clean = plan.golden_batch(B * world, T, 0)
     refs = []
     for r in range(world):
         sd = plan.golden_state(n, ci, 0)
-        refs.append(c_oracle.step(sd, noisy[r * B:(r + 1) * B], clean[r * B:(r + 1) * B], n, ci, True, "mse")["grads"])
-    got = np.load(os.path.join(str(tmp_path), "rank0.npz"))
-    got1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+        refs.append(c_oracle.step(sd, noisy[r * B:(r + 1) * B], clean[r * B:(r + 1) * B], n, ci, True, "mse", precision="f64")["grads"])
+    got = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
     for k in refs[0]:
-        avg = (refs[0][k].astype(np.float64) + refs[1][k].astype(np.float64)) / 2
-        assert np.array_equal(got[k], got1[k]), k
+        avg = sum(ref[k].astype(np.float64) for ref in refs) / world
+        for r in range(1, world):
+            assert np.array_equal(got[0][k], got[r][k]), (k, r)
         if k.endswith(".0.bias") and not k.startswith("out"):
-            assert np.all(got[k] == 0.0)
+            assert np.all(got[0][k] == 0.0)
             continue
         scale = max(np.abs(avg).max(), 1e-6)
-        assert np.abs(got[k] - avg).max() < 3e-4 * scale + 1e-6, (k, np.abs(got[k] - avg).max(), scale)
+        assert np.abs(got[0][k] - avg).max() < 3e-4 * scale + 1e-6, (k, np.abs(got[0][k] - avg).max(), scale)
+        # the per-shard BatchNorm matters: the gradient of the whole batch as ONE shard is a different number
+    whole = c_oracle.step(plan.golden_state(n, ci, 0), noisy, clean, n, ci, True, "mse", precision="f64")["grads"]
+    k = "encoder.1.main.0.weight"
+    avg = sum(ref[k].astype(np.float64) for ref in refs) / world
+    assert np.abs(whole[k] - avg).max() > 1e-3 * np.abs(avg).max()
 
 
 # ---------------------------------------------------------------------------------------------------------------------

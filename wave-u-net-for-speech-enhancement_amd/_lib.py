@@ -16,7 +16,7 @@ EXPORTS = [
     "wunet_loss_backward", "wunet_layer_info", "wunet_num_conv_layers", "wunet_op_conv1d",
     "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
     "wunet_adam_step", "wunet_set_h3", "wunet_op_conv1d_split", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split",
-    "wunet_backward_range_async", "wunet_backward_join", "wunet_debug_set_conv_trace",
+    "wunet_backward_range_async", "wunet_backward_join", "wunet_debug_set_conv_trace", "wunet_crop_windows",
 ]
 
 _vp = ctypes.c_void_p
@@ -54,6 +54,7 @@ def declare(lib):
     lib.wunet_profile_enable.argtypes = [_i]
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
     lib.wunet_profile_collect.restype = ctypes.c_longlong
+    lib.wunet_crop_windows.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp]
     lib.wunet_debug_set_conv_trace.argtypes = [_vp]
     lib.wunet_debug_set_conv_trace.restype = None
     return lib

@@ -15,17 +15,8 @@
         return 0;                                                                                          \
     }
 
-#define WUNET_ILCASE(T, M)                                                                                 \
-    if (il && !bf && taps == T && mrep == M && nseg == 1) {                                                \
-        if (a.NFS != a.NS) return -3;                                                                      \
-        if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<T, M, 1, false, true>), smem) != 0) return -2;            \
-        WUNET_LAUNCH((conv_h3d_kernel<T, M, 1, false, true>), grid, dim3(WUNET_THREADS), smem, st, a);     \
-        return 0;                                                                                          \
-    }
-
-int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool il)
+int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf)
 {
-    WUNET_ILCASE(15, 2) WUNET_ILCASE(15, 3) WUNET_ILCASE(15, 4) WUNET_ILCASE(5, 2) WUNET_ILCASE(5, 3) WUNET_ILCASE(5, 4)
     WUNET_XCASE(15, 2, 1) WUNET_XCASE(15, 3, 1) WUNET_XCASE(15, 4, 1)
     WUNET_XCASE(5, 2, 1) WUNET_XCASE(5, 3, 1) WUNET_XCASE(5, 4, 1)
     WUNET_XCASE(15, 2, 2) WUNET_XCASE(15, 3, 2) WUNET_XCASE(5, 2, 2) WUNET_XCASE(5, 3, 2)

@@ -21,7 +21,7 @@ struct PackDesc {
 #define WUNET_MAX_CONV_LAYERS 34
 struct PackTable { PackDesc d[WUNET_MAX_CONV_LAYERS]; };
 
-__global__ __launch_bounds__(WUNET_THREADS) void pack_weights_kernel(PackTable tab)
+static __global__ __launch_bounds__(WUNET_THREADS) void pack_weights_kernel(PackTable tab)
 {
     const PackDesc& d = tab.d[blockIdx.y];
     const int total = d.mtiles * d.CP * d.taps * 16;
@@ -134,7 +134,7 @@ __device__ __forceinline__ void bn_eval_core(const BnFwdArgs& A, int c)
     A.s[c] = A.beta[c] - A.running_mean[c] * a;
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -186,7 +186,7 @@ __device__ __forceinline__ wunet_f4 wunet_sum_splits4(const float* p, int ksplit
     return v;
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
+static __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
                                                                         size_t split_stride, float* z, int B, int L, int logL,
                                                                         float* stats_rows, int Lt)
 {
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs
 }
 
 // sum of split-K partial tensors (data gradient of the short levels)
-__global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* part, int ksplit, size_t n, float* out,
+static __global__ __launch_bounds__(WUNET_THREADS) void split_sum_kernel(const float* part, int ksplit, size_t n, float* out,
                                                                    const float* bias, int C, int logL)
 {
     if ((n & 3) == 0 && (bias == nullptr || logL >= 2)) {      // 16-byte loads and stores (4 samples of one row)
@@ -276,7 +276,7 @@ struct HeadFwdArgs {
     int B, C, T, logT;
 };
 
-__global__ __launch_bounds__(WUNET_THREADS) void head_fwd_kernel(HeadFwdArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void head_fwd_kernel(HeadFwdArgs A)
 {
     const size_t total = (size_t)A.B * A.T;
     for (size_t p = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; p < total; p += (size_t)gridDim.x * WUNET_THREADS) {
@@ -300,7 +300,7 @@ struct HeadBwdArgs {
     int B, C, T, logT;
 };
 
-__global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const size_t total = (size_t)A.B * A.T;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdArgs A)
 }
 
 // sums partial rows: out[j] = sum_r part[r][j]   (grid = n, one block per column)
-__global__ __launch_bounds__(WUNET_THREADS) void rows_sum_kernel(const float* part, int rows, int n, float* out0, int n0, float* out1)
+static __global__ __launch_bounds__(WUNET_THREADS) void rows_sum_kernel(const float* part, int rows, int n, float* out0, int n0, float* out1)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int j = blockIdx.x;
@@ -546,7 +546,7 @@ struct BnBwdArgs {
     float* bound;        // [C]: |k1| max|g| + |a m2 rstd| max|z - mean| + |a m1|  >=  max |g_z| of the channel
 };
 
-__global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArg
 // the splits are many (up to one per CU), so the work is spread over outputs AND splits: a block owns 16 float4 groups
 // of outputs; its 16 "split lanes" each sum the splits s = lane, lane+16, ... in fp32 groups of 8 and fp64 across
 // groups, and the lanes are combined in lane order through LDS in fp64.
-__global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float* part, int splits, size_t n, float* dw)
+static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(const float* part, int splits, size_t n, float* dw)
 {
     __shared__ double red[16][16][4];
     const int og = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
 }
 
 // max over the per-block activation bounds of an eval-mode conv -> the layer's xb slot (one block)
-__global__ __launch_bounds__(WUNET_THREADS) void xb_reduce_kernel(const float* rows, int n, float* xb)
+static __global__ __launch_bounds__(WUNET_THREADS) void xb_reduce_kernel(const float* rows, int n, float* xb)
 {
     __shared__ float red[WUNET_THREADS];
     float m = 0.0f;
@@ -742,7 +742,7 @@ struct PrepArgs {
                                                          // are carried in rows padded to the next power of two, the padding holds zeros
 };
 
-__global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
 {
     const int l4n = A.L >> 2;
     const size_t total = (size_t)A.B * A.C0 * l4n;
@@ -768,7 +768,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_decim_kernel(PrepArgs A)
 
 // channels [cbeg, cend) of the decoder input: the skip half only depends on an encoder level, so the host
 // runs it on a side stream during the encoder phase and only the upsampled half sits on the critical path
-__global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, int cbeg, int cend)
+static __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, int cbeg, int cend)
 {
     const int l4n = A.L >> 2, C = A.C0 + A.C1, Lh = A.L >> 1, nc = cend - cbeg;
     const size_t total = (size_t)A.B * nc * l4n;
@@ -807,7 +807,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_upcat_kernel(PrepArgs A, i
 
 // g_z = k1*g + k2*z + k3 (BatchNorm backward folded to three per-channel coefficients), materialised once
 // per layer for its data-gradient and weight-gradient GEMMs
-__global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
+static __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                         const float* k3, int C, int logL, size_t n4, float* gz, int Lt)
 {
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
@@ -828,7 +828,35 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_materialize_kernel(const flo
     }
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void fill_kernel(float* p, size_t n, float v)
+// ---------------------------------------------------------------------------- data input: aligned window crops (f4)
+// out[b][j] = flat[starts[b] + j] for the mixture and the clean array alike (the reference's sample_fixed_length_data_aligned,
+// util/utils.py:101-113, for a whole batch).  A window start is any sample, so the loads are dwords (64 consecutive per wave
+// instruction: coalesced, never 16-byte aligned in general); a thread gathers 4 consecutive samples and stores them as one
+// aligned float4 per array when the row length allows it.  HBM-bound: 16 B read + 16 B written per thread.
+static __global__ __launch_bounds__(WUNET_THREADS) void crop_windows_kernel(const float* mix_flat, const float* clean_flat, const long long* starts,
+                                                                            long long total, int length, float* mix, float* clean)
+{
+    const int b = blockIdx.y;
+    long long s0 = starts[b];
+    if (s0 < 0) s0 = 0;                                   // (a corrupt start must not read outside the shard)
+    if (s0 > total - length) s0 = total - length;
+    const int j0 = (blockIdx.x * WUNET_THREADS + threadIdx.x) * 4;
+    if (j0 >= length) return;
+    const float* ms = mix_flat + s0 + j0;
+    const float* cs = clean_flat + s0 + j0;
+    float* md = mix + (size_t)b * length + j0;
+    float* cd = clean + (size_t)b * length + j0;
+    if (j0 + 4 <= length && (length & 3) == 0) {
+        const wunet_f4 m = {ms[0], ms[1], ms[2], ms[3]};
+        const wunet_f4 c = {cs[0], cs[1], cs[2], cs[3]};
+        wunet_st4(md, m);
+        wunet_st4(cd, c);
+    } else {
+        for (int k = 0; k < 4 && j0 + k < length; ++k) { md[k] = ms[k]; cd[k] = cs[k]; }
+    }
+}
+
+static __global__ __launch_bounds__(WUNET_THREADS) void fill_kernel(float* p, size_t n, float v)
 {
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) p[i] = v;
 }
@@ -851,7 +879,7 @@ __device__ __forceinline__ float loss_dterm(int kind, float d)   // derivative w
     return fabsf(d) < 1.0f ? d : sg;
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void loss_partial_kernel(int kind, const float* clean, const float* enh, size_t n, double* part)
+static __global__ __launch_bounds__(WUNET_THREADS) void loss_partial_kernel(int kind, const float* clean, const float* enh, size_t n, double* part)
 {
     __shared__ double red[2 * WUNET_THREADS];
     double s = 0.0, dummy = 0.0;
@@ -861,7 +889,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void loss_partial_kernel(int kind, c
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void loss_final_kernel(const double* part, int rows, size_t n, float* loss)
+static __global__ __launch_bounds__(WUNET_THREADS) void loss_final_kernel(const double* part, int rows, size_t n, float* loss)
 {
     __shared__ double red[2 * WUNET_THREADS];
     double s = 0.0, dummy = 0.0;
@@ -871,7 +899,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void loss_final_kernel(const double*
 }
 
 // grad_enh[i] = gscale[0] * dterm(enh - clean) / n
-__global__ __launch_bounds__(WUNET_THREADS) void loss_bwd_kernel(int kind, const float* clean, const float* enh, const float* gscale, size_t n, float* genh)
+static __global__ __launch_bounds__(WUNET_THREADS) void loss_bwd_kernel(int kind, const float* clean, const float* enh, const float* gscale, size_t n, float* genh)
 {
     const float sc = gscale[0] / (float)n;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS)
@@ -895,7 +923,7 @@ struct AdamTable {
 // gscale: the gradient is multiplied by it first (1/world_size of the data-parallel average folded into the step: the same
 // rounding as a separate g.mul_(1/world) pass).  hyper != nullptr: {step_size, bc2_sqrt} come from device memory
 // (adam_hyper_kernel: the step counter lives on the device, so a captured graph replays the right bias corrections).
-__global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float one_minus_b1, float b2, float one_minus_b2,
+static __global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float one_minus_b1, float b2, float one_minus_b2,
                                                               float bc2_sqrt, float eps, float step_size, float gscale,
                                                               const float* hyper)
 {
@@ -920,7 +948,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void adam_kernel(AdamTable T, float 
 
 // step counter on the device: *step += 1, then the bias-corrected step size lr / (1 - b1^t) and sqrt(1 - b2^t) in double like
 // torch's host arithmetic (one thread)
-__global__ void adam_hyper_kernel(long long* step, double lr, double beta1, double beta2, float* hyper)
+static __global__ void adam_hyper_kernel(long long* step, double lr, double beta1, double beta2, float* hyper)
 {
     const long long t = *step + 1;
     *step = t;

@@ -28,7 +28,8 @@ static __device__ __attribute__((aligned(16))) const unsigned wunet_zero16[8] = 
 // Optional split-K over gridDim.y (short levels: too few position tiles to fill the chip): bias-free partial results
 // [split][B][Cout][L], summed by conv_reduce_bn_kernel / split_sum_kernel like the fp32 path.  Per stage the block stages the W sub-tile (and, for
 // the first tap group of a chunk, the x tile: 4 channel groups x 272 columns, hi and lo) and each wave issues
-// 5 taps x M_REP x 4 tiles x 3 MFMAs.
+// 5 taps x M_REP x 4 tiles x 3 MFMAs.  The kernel is conv_h3d_kernel (wunet_h3d.h); its register-staged predecessor and the
+// paired-tile variant of round 1 / 2 are gone (measurements: DESIGN.md sections 7, 8).
 struct ConvH3Args {
     const wunet_half* xh; const wunet_half* xl;   // [B][C8][L][8]
     const wunet_half* wh; const wunet_half* wl;   // packed
@@ -47,485 +48,6 @@ struct ConvH3Args {
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
     size_t split_stride;                          // floats between the partial results of two splits
 };
-
-// BF: the bf16 mode - the operand arrays hold ONE bf16 word per value (xl / wl unused), a product is one pass of
-// v_mfma_f32_16x16x32_bf16; the LDS tiles and the staging traffic halve.
-template <int TAPS, int M_REP, int NSEG, bool BF = false>
-__global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3_kernel(ConvH3Args A)
-{
-    constexpr int PAD = TAPS / 2;
-    constexpr int TG = 5;                         // taps per stage
-    constexpr int NTG = TAPS / TG;
-    constexpr int LSEG = 256 / NSEG, SW = LSEG + 16;      // samples per segment, its columns incl. the halo of 8 + 8
-    constexpr int COLS = NSEG * SW;               // 272 / 288 / 320
-    constexpr int NPL = BF ? 1 : 2;               // operand planes: hi (+ lo)
-    constexpr int XP = NPL * 4 * COLS;            // 16-byte pieces of the x tile (hi + lo)
-    constexpr int XIT = (XP + WUNET_THREADS - 1) / WUNET_THREADS;     // 9
-    constexpr int WPM = TG * 64;                  // pieces per (m-tile, hi|lo) sub-tile
-    constexpr int WP = NPL * M_REP * WPM;
-    constexpr int WIT = (WP + WUNET_THREADS - 1) / WUNET_THREADS;
-    WUNET_DYN_SMEM(smem);
-    wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS][8]
-    wunet_half* ws = xs + XP * 8;                                      // [hi|lo][M_REP][TG][4][16][8]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
-    // block -> (position tile, row block).  The row blocks of one position tile share its x tile: they get consecutive
-    // slots on ONE XCD (workgroup ids go round-robin over the 8 XCDs), so the tile is fetched into one L2 once.
-    int tile, mblk;
-    if ((A.ntiles & 7) == 0) {
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        mblk = k % A.mblocks;
-        tile = (k / A.mblocks) * 8 + xcd;
-    } else {
-        mblk = blockIdx.x % A.mblocks;
-        tile = blockIdx.x / A.mblocks;
-    }
-    const int n0 = tile * 256;
-    const int b = n0 >> A.logL, l0 = NSEG == 1 ? (n0 & (A.L - 1)) : 0;
-    const int mt0 = mblk * M_REP;
-    const int L = A.L;
-    const bool split = gridDim.y > 1;
-
-    // x slots: piece f -> (which, c8 local, column)
-    int xc8[XIT], xcol[XIT];
-#pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int f = tid + it * WUNET_THREADS;
-        const int r = f % (4 * COLS);
-        xc8[it] = f < XP ? ((r / COLS) | (f >= 4 * COLS ? 8 : 0)) : -1;       // bits 0-2: channel group in the chunk, bit 3: lo array
-        xcol[it] = r % COLS;
-    }
-    // column -> (batch item of the tile, sample): xseg / xl_ of slot it
-#define WUNET_H3_SEG(COL_) ((COL_) / SW)
-#define WUNET_H3_L(COL_) (l0 - 8 + ((COL_) - WUNET_H3_SEG(COL_) * SW))
-    // The MFMA column j of n-tile nt is position wave*64 + 4*j + nt, so a lane ends up with 4 consecutive positions of a
-    // row (one 16-byte store, 256 contiguous bytes per row and wave).  For conflict-free fragment reads the x tile is
-    // kept de-interleaved in LDS: column c of a plane lives at piece (c & 3) * COLS/4 + (c >> 2).
-    // this lane's 4 positions wave*64 + 4*i16 .. +3 lie in ONE batch item of the tile (LSEG >= 4): item lseg, first sample ll0
-    // (LSEG >= 64: the same item for the whole wave; the 32- and 16-sample levels put 2 / 4 items under one wave)
-    const int lpos = wave * 64 + i16 * 4;
-    const int lseg = lpos / LSEG, ll0 = lpos - lseg * LSEG;
-    const int boff = (q * COLS + ((lseg * SW + ll0) >> 2)) * 8;
-    const int aoff = (q * 16 + i16) * 8;
-
-    wunet_f4 acc[M_REP][4];
-#pragma unroll
-    for (int mt = 0; mt < M_REP; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
-
-    wunet_h8 xreg[XIT];
-    const int st_beg = blockIdx.y * A.stages_per_split;
-    const int nstage = (st_beg + A.stages_per_split < A.NCH * NTG) ? st_beg + A.stages_per_split : A.NCH * NTG;
-#define WUNET_H3_PREFETCH(ST_)                                                                                    \
-    {                                                                                                             \
-        const int ch_ = (ST_) / NTG, tg_ = (ST_) - ch_ * NTG;                                                    \
-        if (tg_ == 0 || (ST_) == st_beg) {                                                                        \
-            _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                  \
-                const int c8g_ = ch_ * 4 + (xc8[it] & 7);                                                         \
-                const int l_ = WUNET_H3_L(xcol[it]), bb_ = b + WUNET_H3_SEG(xcol[it]);                            \
-                const bool ok_ = xc8[it] >= 0 && c8g_ < A.C8 && bb_ < A.B && l_ >= 0 && l_ < L;                   \
-                const wunet_half* src_ = (xc8[it] & 8) ? A.xl : A.xh;                                             \
-                xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)bb_ * A.C8 + c8g_) * L + l_) * 8 : 0));             \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    if (st_beg < nstage) WUNET_H3_PREFETCH(st_beg)
-
-    for (int st = st_beg; st < nstage; ++st) {
-        const int ch = st / NTG, tg = st - ch * NTG;
-        wunet_setprio(0);
-        __syncthreads();
-        if (tg == 0 || st == st_beg) {
-#pragma unroll
-            for (int it = 0; it < XIT; ++it) {
-                const int f = tid + it * WUNET_THREADS;
-                const int c8g = ch * 4 + (xc8[it] & 7);
-                const int l = WUNET_H3_L(xcol[it]), bb = b + WUNET_H3_SEG(xcol[it]);
-                const bool ok = xc8[it] >= 0 && c8g < A.C8 && bb < A.B && l >= 0 && l < L;
-                const int pc = (f / COLS) * COLS + (xcol[it] & 3) * (COLS / 4) + (xcol[it] >> 2);
-                if (f < XP) wunet_sth8(xs + (size_t)pc * 8, wunet_selh8(ok, xreg[it]));
-            }
-        }
-        {
-            // the W sub-tile of this stage straight into LDS (the pack is the LDS image: lane-linear DMA); the partner block
-            // on the CU computes while it lands
-#pragma unroll
-            for (int it = 0; it < WIT; ++it) {
-                const int f = tid + it * WUNET_THREADS;
-                if (f < WP) {
-                    const int which = f / (M_REP * WPM), r = f % (M_REP * WPM), mt = r / WPM, p = r % WPM;
-                    const wunet_half* src = which ? A.wl : A.wh;
-                    wunet_dma16(src + ((((size_t)(mt0 + mt) * A.NCH + ch) * TAPS + tg * TG) * 64 + p) * 8,
-                                ws + ((size_t)it * WUNET_THREADS + wave * 64) * 8);
-                }
-            }
-        }
-        wunet_dma_wait();
-        __syncthreads();
-        if (st + 1 < nstage) WUNET_H3_PREFETCH(st + 1)
-        wunet_setprio(3);                         // MFMA phase ahead of the co-resident block's staging instructions (measured: -1 % per step)
-        // B fragments slide: with the interleaved column mapping, fragment (n-tile nt, tap) is column 4*lane + nt + tap,
-        // i.e. F[nt + tap] - each tap needs ONE new fragment pair, not four.
-        wunet_h8 fh[TG + 3], fl[TG + 3];
-#pragma unroll
-        for (int e = 0; e < TG + 3; ++e) {
-            const int ec = tg * TG + e + 8 - PAD;                 // column = 4 * (wave*16 + i16) + ec
-            const int po = ((ec & 3) * (COLS / 4) + (ec >> 2)) * 8;
-            fh[e] = wunet_ldh8(xs + boff + po);
-            if (!BF) fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
-        }
-#pragma unroll
-        for (int tl = 0; tl < TG; ++tl) {
-            wunet_h8 ah[M_REP], al[M_REP];
-#pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt) {
-                ah[mt] = wunet_ldh8(ws + ((mt * TG + tl) * 64) * 8 + aoff);
-                if (!BF) al[mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + tl) * 64 * 8 + aoff);
-            }
-#pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    if (BF) acc[mt][nt] = wunet_mfma16b(ah[mt], fh[tl + nt], acc[mt][nt]);
-                    else {
-                        acc[mt][nt] = wunet_mfma16h(al[mt], fh[tl + nt], acc[mt][nt]);
-                        acc[mt][nt] = wunet_mfma16h(ah[mt], fl[tl + nt], acc[mt][nt]);
-                        acc[mt][nt] = wunet_mfma16h(ah[mt], fh[tl + nt], acc[mt][nt]);
-                    }
-                }
-        }
-    }
-#undef WUNET_H3_PREFETCH
-#undef WUNET_H3_SEG
-#undef WUNET_H3_L
-
-    // ---- epilogue (as conv_mfma_kernel): un-scale, bias, store, BN statistics of the bias-free conv
-    //      (a K split stores its bias-free partial sum; statistics then come from the reduce kernel)
-    const float inv = A.sc ? A.sc[1] : 1.0f, inv2 = A.sc2 ? A.sc2[1] : 1.0f;     // powers of two: exact (applied one after the other: their product may leave fp32's range when the result does not)
-    float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
-    if (A.stats && !split) __syncthreads();       // the W tile's LDS is reused for the statistics hand-over
-    const int bo = b + lseg;
-    float amax = 0.0f;
-    // per-row constants in ONE batch of loads (loaded row by row, each was waited for with vmcnt(0) - together with the previous
-    // row's store: 4*M_REP serialised round trips per block)
-    float bvs[M_REP][4], eas[M_REP][4], ess[M_REP][4];
-#pragma unroll
-    for (int mt = 0; mt < M_REP; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = (mt0 + mt) * 16 + q * 4 + r;
-            bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
-            eas[mt][r] = (A.xrows && co < A.Cout) ? A.ev_a[co] : 0.0f;
-            ess[mt][r] = (A.xrows && co < A.Cout) ? A.ev_s[co] : 0.0f;
-        }
-#pragma unroll
-    for (int mt = 0; mt < M_REP; ++mt) {
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int l = l0 + ll0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = (mt0 + mt) * 16 + q * 4 + r;
-            const float bv = bvs[mt][r];
-            wunet_f4 o;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float v = acc[mt][nt][r] * inv * inv2;
-                s1[r] += v;
-                s2[r] = fmaf(v, v, s2[r]);
-                o[nt] = v + bv;
-            }
-            if (co < A.Cout && bo < A.B) {
-                wunet_st4(outp + ((size_t)bo * A.Cout + co) * L + l, o);
-                if (A.xrows) {
-                    const float ea = eas[mt][r], es = ess[mt][r];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
-                }
-            }
-        }
-        if (A.stats && !split) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s1[r] = wunet_row16_sum(s1[r]);
-                s2[r] = wunet_row16_sum(s2[r]);
-                if (i16 == 0) {                                   // per-wave sums of row mt*16 + q*4 + r -> LDS
-                    float* rp = reinterpret_cast<float*>(ws) + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
-                    rp[0] = s1[r];
-                    rp[1] = s2[r];
-                }
-            }
-        }
-    }
-    if (A.xrows) {                                // eval: block maximum of the activation bound (max is order independent)
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
-        __syncthreads();
-        float* rp = reinterpret_cast<float*>(ws);
-        if (lane == 0) rp[wave] = amax;
-        __syncthreads();
-        if (tid == 0) A.xrows[blockIdx.x] = fmaxf(fmaxf(rp[0], rp[1]), fmaxf(rp[2], rp[3]));
-    }
-    // one statistics row per block (256 positions): the four waves' sums are added in wave order
-    if (A.stats && !split) {
-        __syncthreads();
-        if (tid < M_REP * 16) {
-            const float* rp = reinterpret_cast<const float*>(ws) + tid * 2;
-            float t1 = 0.0f, t2 = 0.0f;
-#pragma unroll
-            for (int w = 0; w < WUNET_WAVES; ++w) {
-                t1 += rp[w * M_REP * 32];
-                t2 += rp[w * M_REP * 32 + 1];
-            }
-            const int co = mt0 * 16 + tid;
-            if (co < A.Cout) {
-                float* stp = A.stats + ((size_t)co * A.ntiles + tile) * 2;
-                stp[0] = t1;
-                stp[1] = t2;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------- conv / data gradient, paired tiles
-// conv_h3_kernel for L >= 256 with TWO adjacent position tiles per block (512 threads: waves 0-3 own tile 2p, waves 4-7 tile
-// 2p+1) sharing ONE copy of the W sub-tile, which is therefore double buffered within the same LDS budget a pair of independent
-// blocks used (2 x tiles + 2 W buffers = 131 KB at M_REP 3, 152 KB at M_REP 4): the DMA of stage s+1's W is issued before the
-// MFMA phase of stage s and has a whole phase to land, instead of being issued and waited for back to back at the top of every
-// stage (the PMC run of round 1 showed 37 % of the wave cycles parked at waitcnt / barrier there), and each W sub-tile crosses
-// L2 -> LDS once per 512 positions instead of once per 256.  The x tiles keep the register prefetch one stage ahead.  Everything
-// else - layouts, fragment order, arithmetic order per output, epilogue - is conv_h3_kernel's: results are bit-identical.
-template <int TAPS, int M_REP>
-__global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3p_kernel(ConvH3Args A)
-{
-    constexpr int PAD = TAPS / 2;
-    constexpr int TG = 5;
-    constexpr int NTG = TAPS / TG;
-    constexpr int COLS = 272;                     // 256 samples + halo of 8 + 8
-    constexpr int XP = 2 * 4 * COLS;              // 16-byte pieces of one x tile (hi + lo)
-    constexpr int XIT = (XP + WUNET_THREADS - 1) / WUNET_THREADS;     // 9 (per half: 256 threads stage their own tile)
-    constexpr int WPM = TG * 64;
-    constexpr int WP = 2 * M_REP * WPM;           // pieces of one W buffer
-    constexpr int NT2 = 2 * WUNET_THREADS;
-    constexpr int WIT = (WP + NT2 - 1) / NT2;
-    WUNET_DYN_SMEM(smem);
-    wunet_half* lds = reinterpret_cast<wunet_half*>(smem);
-    const int tid = threadIdx.x, half = tid >> 8, t = tid & 255;
-    const int lane = tid & 63, wave = tid >> 6, hw = wave & 3, q = lane >> 4, i16 = lane & 15;
-    wunet_half* xs = lds + (size_t)half * XP * 8;                      // this half's x tile [hi|lo][4][COLS][8]
-    wunet_half* wbuf = lds + (size_t)2 * XP * 8;                       // [2 buffers][hi|lo][M_REP][TG][4][16][8]
-
-    // block -> (tile pair, row block): the row blocks of one pair on ONE XCD (they share its x tiles in that L2)
-    const int npair = A.ntiles >> 1;
-    int pair, mblk;
-    if ((npair & 7) == 0) {
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        mblk = k % A.mblocks;
-        pair = (k / A.mblocks) * 8 + xcd;
-    } else {
-        mblk = blockIdx.x % A.mblocks;
-        pair = blockIdx.x / A.mblocks;
-    }
-    const int tile = 2 * pair + half;
-    const int n0 = tile * 256;
-    const int b = n0 >> A.logL, l0 = n0 & (A.L - 1);
-    const int mt0 = mblk * M_REP;
-    const int L = A.L;
-    const bool split = gridDim.y > 1;
-
-    int xc8[XIT], xcol[XIT];
-#pragma unroll
-    for (int it = 0; it < XIT; ++it) {
-        const int f = t + it * WUNET_THREADS;
-        const int r = f % (4 * COLS);
-        xc8[it] = f < XP ? ((r / COLS) | (f >= 4 * COLS ? 8 : 0)) : -1;
-        xcol[it] = r % COLS;
-    }
-    const int lpos = hw * 64 + i16 * 4;
-    const int boff = (q * COLS + (lpos >> 2)) * 8;
-    const int aoff = (q * 16 + i16) * 8;
-
-    wunet_f4 acc[M_REP][4];
-#pragma unroll
-    for (int mt = 0; mt < M_REP; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
-
-    wunet_h8 xreg[XIT];
-    const int st_beg = blockIdx.y * A.stages_per_split;
-    const int nstage = (st_beg + A.stages_per_split < A.NCH * NTG) ? st_beg + A.stages_per_split : A.NCH * NTG;
-#define WUNET_H3P_PREFETCH(ST_)                                                                                   \
-    {                                                                                                             \
-        const int ch_ = (ST_) / NTG, tg_ = (ST_) - ch_ * NTG;                                                    \
-        if (tg_ == 0 || (ST_) == st_beg) {                                                                        \
-            _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                  \
-                const int c8g_ = ch_ * 4 + (xc8[it] & 7);                                                         \
-                const int l_ = l0 - 8 + xcol[it];                                                                 \
-                const bool ok_ = xc8[it] >= 0 && c8g_ < A.C8 && b < A.B && l_ >= 0 && l_ < L;                     \
-                const wunet_half* src_ = (xc8[it] & 8) ? A.xl : A.xh;                                             \
-                xreg[it] = wunet_ldh8(src_ + (ok_ ? (((size_t)b * A.C8 + c8g_) * L + l_) * 8 : 0));               \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    // the W sub-tile of stage ST_ into buffer BUF_: all 512 threads, lane-linear DMA (the pack is the LDS image)
-#define WUNET_H3P_WDMA(ST_, BUF_)                                                                                 \
-    {                                                                                                             \
-        const int ch_ = (ST_) / NTG, tg_ = (ST_) - ch_ * NTG;                                                    \
-        _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
-            const int f_ = tid + it * NT2;                                                                        \
-            if (f_ < WP) {                                                                                        \
-                const int which_ = f_ / (M_REP * WPM), r_ = f_ % (M_REP * WPM), mt_ = r_ / WPM, p_ = r_ % WPM;    \
-                const wunet_half* src_ = which_ ? A.wl : A.wh;                                                    \
-                wunet_dma16(src_ + ((((size_t)(mt0 + mt_) * A.NCH + ch_) * TAPS + tg_ * TG) * 64 + p_) * 8,       \
-                            wbuf + ((size_t)(BUF_) * WP + (size_t)it * NT2 + wave * 64) * 8);                     \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-    if (st_beg < nstage) {
-        WUNET_H3P_WDMA(st_beg, 0)
-        WUNET_H3P_PREFETCH(st_beg)
-    }
-
-    for (int st = st_beg; st < nstage; ++st) {
-        const int ch = st / NTG, tg = st - ch * NTG;
-        const int cur = (st - st_beg) & 1;
-        wunet_setprio(0);
-        __syncthreads();                          // everyone is done with stage st-1's x tile and W buffer
-        if (tg == 0 || st == st_beg) {
-#pragma unroll
-            for (int it = 0; it < XIT; ++it) {
-                const int f = t + it * WUNET_THREADS;
-                const int c8g = ch * 4 + (xc8[it] & 7);
-                const int l = l0 - 8 + xcol[it];
-                const bool ok = xc8[it] >= 0 && c8g < A.C8 && b < A.B && l >= 0 && l < L;
-                const int pc = (f / COLS) * COLS + (xcol[it] & 3) * (COLS / 4) + (xcol[it] >> 2);
-                if (f < XP) wunet_sth8(xs + (size_t)pc * 8, wunet_selh8(ok, xreg[it]));
-            }
-        }
-        wunet_dma_wait();                         // this wave's share of W(st) (issued a whole MFMA phase ago) has landed
-        __syncthreads();
-        if (st + 1 < nstage) {
-            WUNET_H3P_WDMA(st + 1, cur ^ 1)       // lands during this stage's MFMA phase
-            WUNET_H3P_PREFETCH(st + 1)
-        }
-        wunet_setprio(3);
-        const wunet_half* ws = wbuf + (size_t)cur * WP * 8;
-        wunet_h8 fh[TG + 3], fl[TG + 3];
-#pragma unroll
-        for (int e = 0; e < TG + 3; ++e) {
-            const int ec = tg * TG + e + 8 - PAD;
-            const int po = ((ec & 3) * (COLS / 4) + (ec >> 2)) * 8;
-            fh[e] = wunet_ldh8(xs + boff + po);
-            fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
-        }
-#pragma unroll
-        for (int tl = 0; tl < TG; ++tl) {
-            wunet_h8 ah[M_REP], al[M_REP];
-#pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt) {
-                ah[mt] = wunet_ldh8(ws + ((mt * TG + tl) * 64) * 8 + aoff);
-                al[mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + tl) * 64 * 8 + aoff);
-            }
-#pragma unroll
-            for (int mt = 0; mt < M_REP; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    acc[mt][nt] = wunet_mfma16h(al[mt], fh[tl + nt], acc[mt][nt]);
-                    acc[mt][nt] = wunet_mfma16h(ah[mt], fl[tl + nt], acc[mt][nt]);
-                    acc[mt][nt] = wunet_mfma16h(ah[mt], fh[tl + nt], acc[mt][nt]);
-                }
-        }
-    }
-#undef WUNET_H3P_PREFETCH
-#undef WUNET_H3P_WDMA
-
-    // ---- epilogue: conv_h3_kernel's, per half
-    const float inv = A.sc ? A.sc[1] : 1.0f, inv2 = A.sc2 ? A.sc2[1] : 1.0f;
-    float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
-    float* red = reinterpret_cast<float*>(wbuf);               // W buffers are free now: statistics hand-over
-    wunet_setprio(0);
-    if ((A.stats && !split) || A.xrows) __syncthreads();
-    float amax = 0.0f;
-    float bvs[M_REP][4], eas[M_REP][4], ess[M_REP][4];     // (one batch of loads, see conv_h3_kernel)
-#pragma unroll
-    for (int mt = 0; mt < M_REP; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = (mt0 + mt) * 16 + q * 4 + r;
-            bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
-            eas[mt][r] = (A.xrows && co < A.Cout) ? A.ev_a[co] : 0.0f;
-            ess[mt][r] = (A.xrows && co < A.Cout) ? A.ev_s[co] : 0.0f;
-        }
-#pragma unroll
-    for (int mt = 0; mt < M_REP; ++mt) {
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        const int l = l0 + lpos;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int co = (mt0 + mt) * 16 + q * 4 + r;
-            const float bv = bvs[mt][r];
-            wunet_f4 o;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float v = acc[mt][nt][r] * inv * inv2;
-                s1[r] += v;
-                s2[r] = fmaf(v, v, s2[r]);
-                o[nt] = v + bv;
-            }
-            if (co < A.Cout && b < A.B) {
-                wunet_st4(outp + ((size_t)b * A.Cout + co) * L + l, o);
-                if (A.xrows) {
-                    const float ea = eas[mt][r], es = ess[mt][r];
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));
-                }
-            }
-        }
-        if (A.stats && !split) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s1[r] = wunet_row16_sum(s1[r]);
-                s2[r] = wunet_row16_sum(s2[r]);
-                if (i16 == 0) {
-                    float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;
-                    rp[0] = s1[r];
-                    rp[1] = s2[r];
-                }
-            }
-        }
-    }
-    if (A.stats && !split) {
-        __syncthreads();
-        if (t < M_REP * 16) {                     // one statistics row per tile: this half's four waves in wave order
-            const float* rp = red + (half * 4 * M_REP * 16 + t) * 2;
-            float t1 = 0.0f, t2 = 0.0f;
-#pragma unroll
-            for (int w = 0; w < WUNET_WAVES; ++w) {
-                t1 += rp[w * M_REP * 32];
-                t2 += rp[w * M_REP * 32 + 1];
-            }
-            const int co = mt0 * 16 + t;
-            if (co < A.Cout) {
-                float* stp = A.stats + ((size_t)co * A.ntiles + tile) * 2;
-                stp[0] = t1;
-                stp[1] = t2;
-            }
-        }
-    }
-    if (A.xrows) {                                // eval: one activation bound per block (both tiles)
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
-        __syncthreads();
-        if (lane == 0) red[wave] = amax;
-        __syncthreads();
-        if (tid == 0) {
-            float m = red[0];
-#pragma unroll
-            for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
-            A.xrows[blockIdx.x] = m;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------- weight gradient
 // dW[co][ci][t] = sum_{b,p} g_z[b][co][p] * x[b][ci][p + t - PAD] as a GEMM over positions (K) on the fp16 split:

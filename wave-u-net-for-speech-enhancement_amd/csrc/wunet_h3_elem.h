@@ -25,7 +25,7 @@ struct ScaleTable { ScaleDesc d[WUNET_MAX_CONV_LAYERS]; float* wmax; float* slot
 
 // grid (WUNET_WMAX_PARTS, layers): partial max |W| per layer; block (0, layer) also writes the layer's xb (training) or clears
 // it (eval: act_max_kernel accumulates into it with atomicMax)
-__global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTable T)
+static __global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTable T)
 {
     __shared__ float red[WUNET_THREADS];
     const ScaleDesc& d = T.d[blockIdx.y];
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTable T)
 
 // eval mode: xb = max |a_c z + s_c| over the layer (>= |LeakyReLU(.)|), block maxima combined with atomicMax on the bit
 // pattern of the non-negative float (exact and order independent: deterministic)
-__global__ __launch_bounds__(WUNET_THREADS) void act_max_kernel(const float* z, const float* a, const float* s, int C, int logL,
+static __global__ __launch_bounds__(WUNET_THREADS) void act_max_kernel(const float* z, const float* a, const float* s, int C, int logL,
                                                                  size_t n4, float* xb)
 {
     __shared__ float red[WUNET_THREADS];
@@ -98,7 +98,7 @@ __device__ __forceinline__ void wunet_x_scale(const float* xb0, const float* xb1
 
 // fp32 [B][C][L]  ->  hi / lo [B][C8][L][8] halfs of sc[0]*x (sc == nullptr: unscaled).  One thread per
 // (channel group, 4 samples): 8 float4 loads, 4+4 16-byte stores.
-__global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x, wunet_half* hi, wunet_half* lo, const float* sc,
+static __global__ __launch_bounds__(WUNET_THREADS) void split_act_kernel(const float* x, wunet_half* hi, wunet_half* lo, const float* sc,
                                                                    const float* xb0, const float* xb1, float* xsc,
                                                                    int B, int C, int C8, int L, int logL, int bf)
 {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void wgrad_h3_scatter(const WgradH3ReduceArgs& A, siz
 // coalesced 16-byte loads, eight in flight, no LDS, no barrier.  (The 16-split-lane form below spends these layers waiting
 // on two barriers per 16 outputs: 29 us for 33 MB at the 32-sample level.)  fp32 in groups of 8 consecutive splits, fp64
 // across, fixed order.
-__global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_serial_kernel(WgradH3ReduceArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_serial_kernel(WgradH3ReduceArgs A)
 {
     const size_t n4 = (size_t)A.mblocks * A.nblocks * WUNET_WAVES * A.mrep * A.tw * 64;
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n4; i += (size_t)gridDim.x * WUNET_THREADS) {
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_serial_kernel(W
     }
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3ReduceArgs A)
+static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(WgradH3ReduceArgs A)
 {
     __shared__ double red[16][16][4];
     const int og = threadIdx.x & 15, sl = threadIdx.x >> 4;
@@ -384,7 +384,7 @@ struct PrepH3Args {
 };
 
 // One thread = 8 channels of ONE sample, consecutive lanes = consecutive samples: every store instruction of a wave
-// writes 64 x 16 contiguous bytes.  (prep4_h3_kernel below, 4 consecutive samples per thread with 16-byte loads, leaves
+// writes 64 x 16 contiguous bytes.  (The round-1 form - 4 consecutive samples per thread with 16-byte loads - left
 // each store instruction 16-byte pieces at a 64-byte stride; measured with the stores permuted to lane-contiguous and
 // nothing else changed: 37.4 -> 30.3 us average over the upsampling launches, 6.43 -> 6.32 ms per step; this form:
 // 689 -> 523 us of operand passes per step, 6.36 -> 6.19 ms.  The same change to gz_split_h3_kernel, which reads twice
@@ -487,112 +487,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
     }
 }
 
-// The 4-samples-per-thread form (A/B switch WUNET_PREP4).
-__global__ __launch_bounds__(WUNET_THREADS) void prep4_h3_kernel(PrepH3Args A)
-{
-    const int l4n = A.L >> 2, Lh = A.L >> 1, C = A.C0 + A.C1;
-    const int ngrp = A.up_only ? A.C0 / 8 : A.C8;            // channel groups this launch produces
-    const size_t total = (size_t)A.B * ngrp * l4n;
-    float xs_ = 1.0f, xinv_ = 1.0f, ss_ = 1.0f;
-    wunet_x_scale(A.xb0, A.xb1, xs_, xinv_);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { A.xsc[0] = xs_; A.xsc[1] = xinv_; }
-    if (A.kind == 0 && A.sh) { float si_; wunet_x_scale(A.ssb0, A.ssb1, ss_, si_); }
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < total; i += (size_t)gridDim.x * WUNET_THREADS) {
-        const int l4 = (int)(i & (size_t)(l4n - 1));
-        const size_t grow = i >> (A.logL - 2);
-        const int b = (int)(grow / (size_t)ngrp), c8 = (int)(grow - (size_t)b * ngrp);
-        const size_t row = (size_t)b * A.C8 + c8;
-        float v[8][4];
-        float vo[8][4];                        // kind 0 with a skip destination: the odd samples (v holds the even ones)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vo[e][0] = vo[e][1] = vo[e][2] = vo[e][3] = 0.0f;
-        int ui0[4], ui1[4];
-        float ul0[4], ul1[4];
-        if (A.kind != 0) {                     // upsample coordinates of the 4 samples, once for the 8 channels
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wunet_up_coord(4 * l4 + j, Lh, A.up_scale, ui0[j], ui1[j], ul0[j], ul1[j]);
-        }
-        // interior threads: ATen's coordinates of the 4 samples are (2l4-1,2l4) (2l4,2l4+1) (2l4,2l4+1) (2l4+1,2l4+2)
-        const bool win = A.kind != 0 && ui0[0] == 2 * l4 - 1 && ui1[0] == 2 * l4 && ui0[1] == 2 * l4 && ui1[1] == 2 * l4 + 1 &&
-                         ui0[2] == 2 * l4 && ui1[2] == 2 * l4 + 1 && ui0[3] == 2 * l4 + 1 && ui1[3] == 2 * l4 + 2;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c8 * 8 + e;
-            if (c >= C) {
-                v[e][0] = v[e][1] = v[e][2] = v[e][3] = 0.0f;
-            } else if (A.kind == 0) {
-                const float a = A.a0[c], s = A.s0[c];
-                const float* src = A.z0 + ((size_t)b * A.C0 + c) * (size_t)(2 * A.L) + 8 * l4;
-                const wunet_f4 u = wunet_ld4(src), w = wunet_ld4(src + 4);
-                v[e][0] = wunet_lrelu(a * u[0] + s); v[e][1] = wunet_lrelu(a * u[2] + s);
-                v[e][2] = wunet_lrelu(a * w[0] + s); v[e][3] = wunet_lrelu(a * w[2] + s);
-                if (A.sh) {
-                    vo[e][0] = wunet_lrelu(a * u[1] + s); vo[e][1] = wunet_lrelu(a * u[3] + s);
-                    vo[e][2] = wunet_lrelu(a * w[1] + s); vo[e][3] = wunet_lrelu(a * w[3] + s);
-                }
-            } else if (c < A.C0) {
-                const float a = A.a0[c], s = A.s0[c];
-                const float* zr = A.z0 + ((size_t)b * A.C0 + c) * Lh;
-                if (win) {
-                    // the four samples 4*l4 .. 4*l4+3 read the source window [2*l4-1, 2*l4+2] (checked above against the
-                    // exact coordinates): three loads instead of eight
-                    const float w0 = zr[2 * l4 - 1], w3 = zr[2 * l4 + 2];
-                    const float2 w12 = *reinterpret_cast<const float2*>(zr + 2 * l4);
-                    const float t0 = wunet_lrelu(a * w0 + s), t1 = wunet_lrelu(a * w12.x + s), t2 = wunet_lrelu(a * w12.y + s),
-                                t3 = wunet_lrelu(a * w3 + s);
-                    v[e][0] = ul0[0] * t0 + ul1[0] * t1;
-                    v[e][1] = ul0[1] * t1 + ul1[1] * t2;
-                    v[e][2] = ul0[2] * t1 + ul1[2] * t2;
-                    v[e][3] = ul0[3] * t2 + ul1[3] * t3;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[e][j] = ul0[j] * wunet_lrelu(a * zr[ui0[j]] + s) + ul1[j] * wunet_lrelu(a * zr[ui1[j]] + s);
-                }
-            } else {
-                const int cs = c - A.C0;
-                const float a = A.a1[cs], s = A.s1[cs];
-                const wunet_f4 u = wunet_ld4(A.z1 + ((size_t)b * A.C1 + cs) * A.L + 4 * l4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[e][j] = wunet_lrelu(a * u[j] + s);
-            }
-        }
-        wunet_half* ph = A.xh + (row * A.L + 4 * (size_t)l4) * 8;
-        wunet_half* pl = A.xl + (row * A.L + 4 * (size_t)l4) * 8;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wunet_h8 h, l;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                wunet_half a, d;
-                wunet_split_rt(A.bf, xs_ * v[e][j], a, d);
-                wunet_put_half(h, e, a);
-                wunet_put_half(l, e, d);
-            }
-            wunet_sth8(ph + 8 * j, h);
-            if (!A.bf) wunet_sth8(pl + 8 * j, l);
-        }
-        if (A.kind == 0 && A.sh) {
-            // skip half of the decoder input at the producer's resolution (2L): samples 8*l4 .. 8*l4+7 = even/odd interleaved
-            const size_t srow = (size_t)b * A.SC8 + A.sc8off + c8;
-            wunet_half* qh = A.sh + (srow * (size_t)(2 * A.L) + 8 * (size_t)l4) * 8;
-            wunet_half* ql = A.sl + (srow * (size_t)(2 * A.L) + 8 * (size_t)l4) * 8;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                wunet_h8 h, l;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    wunet_half a, d;
-                    wunet_split_rt(A.bf, ss_ * ((j & 1) ? vo[e][j >> 1] : v[e][j >> 1]), a, d);
-                    wunet_put_half(h, e, a);
-                    wunet_put_half(l, e, d);
-                }
-                wunet_sth8(qh + 8 * j, h);
-                if (!A.bf) wunet_sth8(ql + 8 * j, l);
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------- weight pack
 // dst[mt][stage][slot][q][i][e], 5 slots per stage.  Full stage (chunk ch of 32 K channels, tap group tg; stage = ch * taps/5 + tg):
 // W(row = mt*16+i, k-channel = ch*32+q*8+e, tap = tg*5+slot) - i.e. [mt][chunk][tap][q][i][e].  Tail stage g (ntt > 0; after the
@@ -615,7 +509,7 @@ struct PackH3Desc {
 };
 struct PackH3Table { PackH3Desc d[WUNET_MAX_CONV_LAYERS]; };
 
-__global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
+static __global__ __launch_bounds__(WUNET_THREADS) void pack_h3_kernel(PackH3Table tab)
 {
     const PackH3Desc& d = tab.d[blockIdx.y];
     const int ntg = d.taps / 5, ns = d.ntt ? d.ns : d.nch * ntg, nfs = d.ntt ? d.nfull * ntg : ns;

@@ -23,12 +23,9 @@
 #include "wunet_h3.h"
 
 
-// IL: the DMA pieces of the next stage are issued BETWEEN the MFMA passes of the current one, predicated inside their asm statements
-// (no branch in the stage body: one basic block, so the address arithmetic of a piece is scheduled into the issue slots the
-// matrix pipe leaves free) instead of in two blocks of pieces behind uniform branches; the phase stamps are compiled out.
 // (no tail stages in the two shapes at the register limit: they would spill)
 #define WUNET_H3D_HAS_TAIL(M_REP_, NSEG_) ((M_REP_) < 4 && (NSEG_) < 16)
-template <int TAPS, int M_REP, int NSEG, bool BF = false, bool IL = false>
+template <int TAPS, int M_REP, int NSEG, bool BF = false>
 __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A)
 {
     constexpr int PAD = TAPS / 2;
@@ -159,7 +156,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         TILE_ = (V_) / A.mblocks;                                                                                 \
     }
 #define WUNET_H3D_STAMP(K_)                                                                                       \
-    if (!IL && A.trace) {                                                                                                \
+    if (A.trace) {                                                                                                       \
         const unsigned long long t_ = wunet_memtime();                                                            \
         if (tid == 0 && (K_) < 64) A.trace[(size_t)blockIdx.x * 64 + (K_)] = t_;                                  \
     }
@@ -240,70 +237,6 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             else if ((WHICH_) == 1) acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fl[(TL_) + nt], acc[mt][nt]);       \
             else acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);                          \
         }
-            if (IL) {
-                WUNET_H3D_LOAD_F(false)
-                WUNET_H3D_LOAD_A(0, 0)
-                // ---- one basic block: pieces of the next x tile after passes 0 .. 9, of the next W sub-tile after passes 10 .. 14
-                constexpr int XPS = (XIT + 9) / 10, WPS = (WIT + 4) / 5;
-                const int xn = x_next ? 1 : 0, hn = has_next ? 1 : 0;
-                const int xb_ = last ? nb : b, xl0_ = last ? nl0 : l0, wmt0_ = last ? nmt0 : mt0;
-                const long long xoff_ = (long long)((((size_t)xb_ * A.C8 + nch * 4) * L + xl0_) * 16);
-                const long long xh_ = (long long)reinterpret_cast<size_t>(A.xh) + xoff_, xl_ = (long long)reinterpret_cast<size_t>(A.xl) + xoff_;
-                const long long woff_ = (long long)((((size_t)wmt0_ * A.NS + nst) * TG * 64) * 16);
-                const long long wh_ = (long long)reinterpret_cast<size_t>(A.wh) + woff_, wl_ = (long long)reinterpret_cast<size_t>(A.wl) + woff_;
-                unsigned valid = m_live;
-                valid &= ~((NSEG > 1 || xl0_ == 0) ? m_lo : 0u);
-                valid &= ~((NSEG > 1 || xl0_ + 256 >= L) ? m_hi : 0u);
-                {
-                    const int c8lim = A.C8 - nch * 4, blim = A.B - xb_;
-#pragma unroll
-                    for (int it = 0; it < XIT; ++it) {
-                        const bool ok = (int)((c8pk >> (2 * it)) & 3) < c8lim && (NSEG == 1 || (int)((segpk >> (4 * it)) & 15) < blim);
-                        valid &= ~((ok ? 0u : 1u) << it);
-                    }
-                }
-                wunet_wait_lds_barrier_if(xn);    // every wave holds its B fragments: the x tile is free
-#define WUNET_H3D_SLOT(S_)                                                                                        \
-    {                                                                                                             \
-        if ((S_) < 10) {                                                                                          \
-            _Pragma("unroll") for (int it = (S_) * XPS; it < ((S_) + 1) * XPS && it < XIT; ++it) {                \
-                int o_ = xoffb[it];                                                                               \
-                wunet_opaque(o_);                                                                                 \
-                const bool lo_ = it < NPL * XF ? it / XF != 0 : ((m_pl >> it) & 1) != 0;                          \
-                const long long real_ = (lo_ ? xl_ : xh_) + o_;                                                   \
-                const long long a_ = (valid >> it) & 1 ? real_ : zero_a;                                          \
-                const int run_ = it < NPL * XF ? 4 * (it % XF) + wave_u : wunet_uniform(xrun);                    \
-                const int pl_ = it < NPL * XF ? it / XF : wunet_uniform((m_pl >> it) & 1);                        \
-                const int pr_ = it < NPL * XF ? xn : (xn & wunet_uniform((int)((m_live >> it) & 1)));             \
-                wunet_dma16a_if(pr_, reinterpret_cast<const void*>(a_), xs_a + (pl_ * 4 * COLS + run_ * 64) * 16); \
-            }                                                                                                     \
-        } else {                                                                                                  \
-            _Pragma("unroll") for (int it = ((S_) - 10) * WPS; it < ((S_) - 9) * WPS && it < WIT; ++it) {         \
-                int m_ = woff[it];                                                                                \
-                wunet_opaque(m_);                                                                                 \
-                const long long a_ = ((m_ >> 30) & 1 ? wl_ : wh_) + (long long)(m_ & 0x3fffffff) * 2;             \
-                const int pr_ = (it + 1) * WUNET_THREADS <= WP ? hn : (hn & wunet_uniform((int)(tid + it * WUNET_THREADS < WP))); \
-                wunet_dma16a_if(pr_, reinterpret_cast<const void*>(a_), ws_a + (it * WUNET_THREADS + wave_u * 64) * 16); \
-            }                                                                                                     \
-        }                                                                                                         \
-    }
-#pragma unroll
-                for (int tl = 0; tl < TG; ++tl) {
-                    if (tl + 1 < TG) {
-                        if (tl & 1) { WUNET_H3D_LOAD_A(0, tl + 1) } else { WUNET_H3D_LOAD_A(1, tl + 1) }
-                    }
-                    wunet_sched_fence();
-                    if (tl & 1) { WUNET_H3D_PASS(0, 1, tl) } else { WUNET_H3D_PASS(0, 0, tl) }
-                    if (tl == TG - 2) wunet_wait_lds_barrier();       // the last A fragments have landed in every wave: the W sub-tile is free
-                    WUNET_H3D_SLOT(3 * tl)
-                    if (tl & 1) { WUNET_H3D_PASS(1, 1, tl) } else { WUNET_H3D_PASS(1, 0, tl) }
-                    WUNET_H3D_SLOT(3 * tl + 1)
-                    if (tl & 1) { WUNET_H3D_PASS(2, 1, tl) } else { WUNET_H3D_PASS(2, 0, tl) }
-                    WUNET_H3D_SLOT(3 * tl + 2)
-                }
-#undef WUNET_H3D_SLOT
-                continue;
-            }
             // After the B fragments: the x tile is free once every wave holds them; the prefetch of the next step's A fragments is
             // ISSUED at the fence, not sunk to its first use; with the last A fragments of the stage in flight the W sub-tile is free
             // once every wave has them.  A tail stage runs the first NTT steps only.

@@ -12,11 +12,10 @@
 #define WUNET_ALLOW_BIG_LDS(kern, smem)                                                                    \
     ([&]() -> int {                                                                                        \
         static size_t granted[64];                                                                         \
-        static const bool always = getenv("WUNET_ATTR_ALWAYS") != nullptr;     /* A/B switch */            \
         if ((size_t)(smem) <= 64 * 1024) return 0;                                                         \
         int dev = 0;                                                                                       \
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0, granted[0] = 0;             \
-        if (!always && (size_t)(smem) <= granted[dev]) return 0;                                           \
+        if ((size_t)(smem) <= granted[dev]) return 0;                                                      \
         const int e = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&kern),                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(smem));   \
         if (e == 0) granted[dev] = (size_t)(smem);                                                         \
@@ -37,7 +36,5 @@ struct ConvH3Args;
 struct WgradH3Args;
 struct WgradH3dArgs;
 int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st, bool bf, int tp);
-int wunet_launch_conv_h3(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf);
-int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool il);
-int wunet_launch_conv_h3p(const ConvH3Args& a, int taps, int mrep, dim3 grid, size_t smem, hipStream_t st);
+int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf);
 int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st, bool bf);

@@ -1,0 +1,530 @@
+// Shape planning, workspace layout, context life cycle, error text and the per-launch profiler of libwunet_hip.so
+// (see wunet_host.h for the map of the host side).
+#include "wunet_host.h"
+#include "wunet_h3_elem.h"      // WUNET_SLOT_FLOATS, WUNET_WMAX_PARTS
+
+namespace wunet_host {
+
+namespace { thread_local std::string g_err; }
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+const char* last_error_text() { return g_err.c_str(); }
+
+// ---- optional per-launch profiler (HIP events on the launch stream), used by bench.py's roofline leg
+namespace {
+struct ProfRec { std::string name; double flops; double bytes; hipEvent_t e0, e1; };
+std::vector<ProfRec> g_prof;
+}
+bool g_prof_on = false;
+unsigned long long* g_h3_trace = nullptr;
+
+#ifdef WUNET_EMU
+void prof_begin(hipStream_t, const char*, double, double) {}
+void prof_end(hipStream_t) {}
+long long prof_collect(char* buf, size_t cap)
+{
+    if (cap) buf[0] = 0;
+    return 0;
+}
+#else
+void prof_begin(hipStream_t st, const char* name, double flops, double bytes)
+{
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    hipEventCreate(&r.e0);
+    hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, st);
+    g_prof.push_back(r);
+}
+void prof_end(hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEventRecord(g_prof.back().e1, st);
+}
+// One line per kernel name: "name\tlaunches\ttotal_ms\ttotal_flops\ttotal_bytes\n"; clears the records.  Synchronises the device.
+long long prof_collect(char* buf, size_t cap)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return fail(WUNET_E_RUNTIME, "hipDeviceSynchronize");
+    struct Agg { std::string name; long n; double ms, fl, by; };
+    std::vector<Agg> agg;
+    for (ProfRec& r : g_prof) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        hipEventDestroy(r.e0);
+        hipEventDestroy(r.e1);
+        size_t k = 0;
+        for (; k < agg.size(); ++k) if (agg[k].name == r.name) break;
+        if (k == agg.size()) agg.push_back(Agg{r.name, 0, 0.0, 0.0, 0.0});
+        agg[k].n += 1; agg[k].ms += ms; agg[k].fl += r.flops; agg[k].by += r.bytes;
+    }
+    g_prof.clear();
+    std::string out;
+    char line[256];
+    for (const Agg& a : agg) {
+        snprintf(line, sizeof line, "%s\t%ld\t%.6f\t%.6e\t%.6e\n", a.name.c_str(), a.n, a.ms, a.fl, a.by);
+        out += line;
+    }
+    if (cap == 0) return 0;
+    const size_t nb = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), nb);
+    buf[nb] = 0;
+    return (long long)nb;
+}
+#endif
+
+// m-tiles (16 output channels each) handled per block: minimise zero padding, prefer bigger blocks.
+int pick_mrep(int mtiles, int max_rep)
+{
+    // minimise zero padding; among equals prefer 4 then 3 accumulator rows per wave: measured on MI355X the
+    // smaller register footprint (3 waves per SIMD instead of 2) beats the extra re-staging of the x tile
+    static const int order[5] = {4, 3, 5, 6, 2};
+    int best = 2, best_pad = 1 << 30;
+    for (int k = 0; k < 5; ++k) {
+        const int r = order[k];
+        if (r > max_rep) continue;
+        const int pad = round_up(mtiles, r) - mtiles;
+        if (pad < best_pad) { best_pad = pad; best = r; }
+    }
+    return best;
+}
+ConvCfg plan_conv(int B, int L, int rows, int kch, int taps)
+{
+    ConvCfg c{};
+    const int kc = kc_of(taps);
+    const int mt = (rows + 15) / 16;
+    c.mrep = pick_mrep(mt, 6);
+    c.mtiles_p = round_up(mt, c.mrep);
+    c.mblocks = c.mtiles_p / c.mrep;
+    c.cp = round_up(kch, kc);
+    const long long pos = (long long)B * L;
+    const int nchunks = c.cp / kc;
+    // 256-position tiles (N_REP=4) reuse every A fragment 4x; usable when the staged row fits the loader
+    // (k15: L >= 16, k5: L >= 64) and - counting the split-K factor available - the grid still fills the chip
+    const bool wide_ok = (taps == 15 ? L >= 16 : L >= 64) && pos >= 256;
+    const long long tiles4 = ((pos + 255) / 256) * c.mblocks;
+    const int ksmax = nchunks >= 4 ? (nchunks / 2 < 16 ? nchunks / 2 : 16) : 1;
+    c.nrep = (wide_ok && tiles4 * ksmax >= 256) ? 4 : 1;
+    const int tn = 64 * c.nrep;
+    c.grid_x = (int)((pos + tn - 1) / tn);
+    // split-K over input-channel chunks when there are too few (position, m-block) tiles to fill 256 CUs
+    const int blocks = c.grid_x * c.mblocks;
+    c.ksplit = 1; c.kcps = c.cp;
+    if (blocks < 192 && nchunks >= 4) {
+        const int want = (512 + blocks - 1) / blocks;
+        int cps = (nchunks + want - 1) / want;
+        if (cps < 2) cps = 2;
+        const int ks = (nchunks + cps - 1) / cps;
+        if (ks > 1) { c.ksplit = ks; c.kcps = cps * kc; }
+    }
+    return c;
+}
+WgradCfg plan_wgrad(int B, int L, int cin, int cout, int taps)
+{
+    WgradCfg w{};
+    const int mt = (cout + 15) / 16;
+    const int nt = taps == 15 ? cin : (cin + 2) / 3;         // n-tiles of 16 (ci,tap) columns
+    const long long chunks = ((long long)B * L + 63) / 64;
+    const bool big = L >= 64;
+    if (taps == 15 && cin == 1) {
+        // encoder[0]: a single n-tile - the four waves split the K steps instead
+        w.wsplit = 1; w.nw = 1; w.xit = 1;
+        w.mrep = pick_mrep(mt, 6);
+        w.mblocks = round_up(mt, w.mrep) / w.mrep;
+        w.nblocks = 1;
+    } else {
+        const int nws[2] = {taps == 15 ? 6 : 2, (taps == 5 && big) ? 6 : 0};
+        long long best = -1; int best_area = 0;
+        for (int k = 0; k < 2; ++k) {
+            const int nw = nws[k];
+            if (!nw) continue;
+            for (int mr = 2; mr <= 6; ++mr) {
+                if (mr * nw > 36) continue;
+                const long long padded = (long long)round_up(mt, mr) * round_up(nt, 4 * nw);
+                if (best < 0 || padded < best || (padded == best && mr * nw > best_area)) {
+                    best = padded; best_area = mr * nw; w.mrep = mr; w.nw = nw;
+                }
+            }
+        }
+        w.wsplit = 0;
+        w.mblocks = round_up(mt, w.mrep) / w.mrep;
+        w.nblocks = round_up(nt, 4 * w.nw) / (4 * w.nw);
+        w.xit = big ? (w.nw == 6 && taps == 5 ? 6 : 2) : 8;
+    }
+    // split-K: one resident wave of equal-work blocks.  Residency estimate: accumulators + staging registers
+    // against the 512-entry register file per SIMD lane, and the LDS footprint against 160 KiB.
+    {
+        const int regs = 4 * w.mrep * w.nw + 72 + 4 * (w.mrep + w.xit);
+        int occ = regs <= 168 ? 3 : (regs <= 256 ? 2 : 1);
+        const int segw = (L < 64 ? L : 64) + 16;
+        const int rowp = (64 / (L < 64 ? L : 64)) * segw + (taps == 5 ? 24 : 0);
+        const int cib = w.wsplit ? 1 : 4 * w.nw * (taps == 15 ? 1 : 3);
+        const long long lds = ((long long)w.mrep * 16 * 66 + (long long)cib * rowp) * 4;
+        const int occ_lds = (int)(160 * 1024 / lds);
+        if (occ_lds < occ) occ = occ_lds < 1 ? 1 : occ_lds;
+        const long long slots = 256LL * occ;
+        const long long mn = (long long)w.mblocks * w.nblocks;
+        long long ks = slots / mn;
+        if (ks < 1) ks = 1;
+        if (ks > chunks) ks = chunks;
+        w.ksplit = (int)ks;
+        w.cps = (int)((chunks + ks - 1) / ks);
+        // drop splits that would only run padding chunks
+        w.ksplit = (int)((chunks + w.cps - 1) / w.cps);
+    }
+    w.rows = w.ksplit * (w.wsplit ? 4 : 1);
+    return w;
+}
+// blocks per layer of the weight-pack launches (grid-stride loops inside)
+unsigned pack_gx() { return 512; }      // (swept 64 .. 1024 in round 1: 6.19 -> 6.13 ms per step at 512)
+
+int pick_mrep_h3(int mtiles, const char* env, const char* dflt)
+{
+    int best = 2, best_pad = 1 << 30;
+    const char* ord = env ? getenv(env) : nullptr;    // test hook (WUNET_H3_ORDER / _H3D_ORDER / _H3W_ORDER): tiny shapes reach every rows-per-wave instantiation
+    if (!ord) ord = dflt;
+    for (const char* p = ord; *p; ++p) {
+        const int m = *p - '0';
+        const int pad = round_up(mtiles, m) - mtiles;
+        if (pad < best_pad) { best_pad = pad; best = m; }
+    }
+    return best;
+}
+
+// Preference order of the accumulator rows per wave (16 * M_REP output rows per block) of conv_h3d_kernel.  3 and 2 keep the
+// most blocks resident; 4 (no padding for 8 m-tiles, a third fewer re-reads of the x tile) wins on the 5-tap layers while
+// the grid still has two blocks for every CU (measured per layer: decoder.7 forward 73.6 -> 65.9 us, decoder.10 data
+// gradient 166.7 -> 141.4 us; at 256 samples the same choice leaves CUs idle: 35.7 -> 49.6 us) and is neutral on 15 taps.
+const char* h3_order(int taps, int L, int ntiles, int mtiles)
+{
+    return (taps == 5 && L >= 256 && (long long)ntiles * ((mtiles + 3) / 4) >= 512) ? "432" : "32";
+}
+
+// floats of one split's tile-major partial dW (wgrad_h3_kernel epilogue): padded tiles
+size_t h3w_part_stride(const LayerPlan& l)
+{
+    const int tw = l.taps == 15 ? 8 : 5;
+    return (size_t)l.h3w_mblocks * l.h3w_nblocks * WUNET_WAVES * l.h3w_mrep * tw * 256;
+}
+
+// conv_h3d_kernel split-K: with fewer than ~1.5 blocks per CU the K stages are split so that about two blocks per CU
+// exist; returns the stages per split (== nstage: no split).
+int h3_stages_per_split(int blocks, int nstage)
+{
+    if (blocks >= 384 || nstage <= 1 || getenv("WUNET_H3_NOSPLIT")) return nstage;      // (switch: tests reach the un-split epilogue on small shapes)
+    int ks = (512 + blocks - 1) / blocks;
+    if (ks > nstage) ks = nstage;
+    return (nstage + ks - 1) / ks;
+}
+
+// K tail of conv_h3d_kernel: with c8 = 4 nfull + t1 groups of 8 K channels, the t1 left-over groups run one tail stage each (the taps
+// spread over the four K quarters of the MFMA: ceil(taps / 4) steps) instead of one chunk padded with zeros (taps steps).  Worth it
+// for 15 taps with any tail (4 t1 steps instead of 15), for 5 taps with one left-over group (2 instead of 5).
+// Returns the steps of a tail stage, 0 without a tail.  WUNET_H3_KTAIL=0 (read when a context is planned): the padded chunk
+// everywhere - the other arm of tests/test_gpu_parity.py::test_k_tail_on_hardware; the two shapes at the register limit always run it
+int h3_tail_steps(int kch, int taps)
+{
+    const char* kt = getenv("WUNET_H3_KTAIL");
+    const int t1 = ((kch + 7) / 8) & 3;
+    if (kt && atoi(kt) == 0) return 0;
+    return taps == 15 ? (t1 ? 4 : 0) : (t1 == 1 ? 2 : 0);
+}
+// stages of the K loop: full chunks * tap groups + tail stages
+int h3_stage_count(int kch, int taps, int ntt)
+{
+    const int c8 = (kch + 7) / 8;
+    return ntt ? (c8 / 4) * (taps / 5) + (c8 & 3) : ((c8 + 3) / 4) * (taps / 5);
+}
+
+H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* order_env, int bf)
+{
+    H3ConvPlan p{};
+    const long long posn = (long long)B * L;
+    p.ntiles = (int)((posn + 255) / 256);
+    const int ntg = taps / 5, c8 = (kch + 7) / 8, mt = (rows + 15) / 16;
+    // (4 accumulator rows per wave only exist un-segmented: L >= 256)
+    p.mrep = pick_mrep_h3(mt, L >= 256 ? order_env : nullptr, h3_order(taps, L, p.ntiles, mt));
+    p.mtp = round_up(mt, p.mrep);
+    p.nch = (c8 + 3) / 4;
+    p.ntt = (p.mrep < 4 && L >= 32) ? h3_tail_steps(kch, taps) : 0;      // (WUNET_H3D_HAS_TAIL: the shapes at the register limit go without)
+    const int ns = h3_stage_count(kch, taps, p.ntt);
+    p.sps = h3_stages_per_split(p.ntiles * (p.mtp / p.mrep), ns);
+    p.ksplit = (ns + p.sps - 1) / p.sps;
+    (void)ntg; (void)bf;
+    return p;
+}
+
+// Tiling of the split weight gradient of one layer (fills l.h3w_*)
+void plan_h3_wgrad(LayerPlan& l, int B)
+{
+    const int mt = (l.cout + 15) / 16, cib = l.taps == 15 ? 32 : 64;
+    // 3 or 2 m-tiles per block: those DMA-staged kernels fit two blocks per CU, and two independent blocks beat taller
+    // single blocks (weight gradients 1.25 -> 1.14 ms per step; the register-staged kernel preferred 5-6 m-tiles)
+    // per-layer sweep (profiles/r1_h3_rows_per_wave_sweep.txt): 4 where 5 taps divide evenly at >= 256 samples
+    // (decoder.7: 79 -> 68 us); 2 on the short 15-tap levels (encoder.6/7/9: 44 -> 39, 32 -> 29, 21 -> 18 us)
+    // (round-2 sweep, profiles/r2_wgrad_rows_sweep.txt: 5 m-tiles in one block - no padded rows - win on the 15-tap layer with
+    // Cout = 80 .. 72 at >= 1024 samples (encoder.2: 118 -> 106 us) although that kernel runs one block per CU)
+    const char* w_order = (l.taps == 5 && l.L >= 256 && mt % 4 == 0) ? "432" : (l.taps == 15 && l.L <= 256) ? "2" :
+                          (l.taps == 15 && mt == 5 && l.L >= 1024) ? "532" : "32";
+    l.h3w_mrep = pick_mrep_h3(mt, "WUNET_H3W_ORDER", w_order);
+    l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
+    l.h3w_nblocks = (l.cin + cib - 1) / cib;
+    // 128 positions per K chunk (256 measured 5-8 % faster for the kernel alone and slower in the concurrent step, 64-position
+    // double-buffered chunks neutral: DESIGN.md sections 7, 8)
+    l.h3w_tp = 128;
+    // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 up to 3
+    const bool sb2 = l.L >= 128 && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
+    const long long slots = 256LL * ((l.h3w_mrep <= 2 || sb2) ? 2 : 1);      // resident blocks: launch bounds of the wgrad kernels
+    long long ks = slots / ((long long)l.h3w_mblocks * l.h3w_nblocks);
+    if (ks < 1) ks = 1;
+    const long long chunks = ((long long)B * l.L + l.h3w_tp - 1) / l.h3w_tp;
+    if (ks > chunks) ks = chunks;
+    l.h3w_cps = (int)((chunks + ks - 1) / ks);
+    l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
+}
+
+void layout_workspace(wunet_ctx* c)
+{
+    const int B = c->B, T = c->T, ci = c->ci;
+    size_t off = 0, wpk = 0, stats_max = 0, spart_max = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        l.f = plan_conv(B, l.L, l.cout, l.cin, l.taps);
+        l.d = plan_conv(B, l.L, l.cin, l.cout, l.taps);
+        l.w = plan_wgrad(B, l.L, l.cin, l.cout, l.taps);
+        if (l.L < 4) { l.f.ksplit = 1; l.d.ksplit = 1; }    // levels of 1-2 samples run the scalar kernels of wunet_tiny.h
+        {
+            // auto: only where the fp32 planner would launch an un-split full-width grid (enough 256-position tiles to fill
+            // the chip); forced (2): every level the kernels can run (tests of small shapes)
+            l.first = (i == 0 && l.cin == 1 && l.taps == 15 && l.L >= 256) ? 1 : 0;
+            // fp16-split kernels.  auto (1): levels >= 256 samples where the fp32 planner would launch an un-split
+            // full-width grid (enough 256-position tiles to fill the chip) and the 128- to 16-sample levels of a large
+            // batch (split-K fills the chip there); forced (2): every level the kernels can run (tests of small shapes)
+            const long long posn = (long long)B * l.L;
+            // (the 16-sample level: 20-38 us per step faster on conv_h3d_kernel<., ., 16> than on the fp32 kernels)
+            const int min_l = 16;
+            const bool big = c->h3 && !l.first && l.L >= 16 && posn >= 256 &&
+                             (c->h3 == 2 || (l.L >= 256 ? (l.f.nrep == 4 && l.f.ksplit == 1) : (l.L >= min_l && posn >= 1024)));
+            l.h3f = big ? 1 : 0;
+            // backward: data gradient AND weight gradient together (g_z then only exists in the split layout)
+            l.h3d = (big && i > 0 && l.cin >= 16 && (c->h3 == 2 || l.L < 256 || (l.d.nrep == 4 && l.d.ksplit == 1))) ? 1 : 0;
+            l.h3w = l.h3d;
+            l.h3x = l.h3w;        // ... and so does the conv input (no fp32 xin)
+            if (l.h3f) {
+                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cout, l.cin, l.taps, "WUNET_H3_ORDER", c->bf);
+                l.h3f_mrep = p.mrep; l.h3f_mtp = p.mtp; l.h3f_nch = p.nch; l.h3f_sps = p.sps; l.h3f_ntt = p.ntt;
+                l.f.ksplit = p.ksplit;
+                l.f.grid_x = p.ntiles;                 // one statistics row per tile (f_rows below)
+            }
+            if (l.h3d) {
+                const H3ConvPlan p = plan_h3_conv(B, l.L, l.cin, l.cout, l.taps, "WUNET_H3D_ORDER", c->bf);
+                l.h3d_mrep = p.mrep; l.h3d_mtp = p.mtp; l.h3d_nch = p.nch; l.h3d_sps = p.sps; l.h3d_ntt = p.ntt;
+                l.d.ksplit = p.ksplit;
+            }
+            if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
+        }
+        l.f_rows = l.h3f ? l.f.grid_x : l.f.grid_x * WUNET_WAVES;
+        l.f_wpk = wpk;
+        wpk += align64((size_t)l.f.mtiles_p * l.f.cp * l.taps * 16);
+        if (l.f.ksplit == 1 && (size_t)l.f_rows * l.cout * 2 > stats_max) stats_max = (size_t)l.f_rows * l.cout * 2;
+        // (a padded length takes every conv but the first through the bias-free buffer and conv_reduce_bn_kernel: its statistics skip
+        // the row padding, the conv kernels need not know)
+        if ((l.f.ksplit > 1 || c->padded) && (size_t)64 * l.cout * 2 > stats_max) stats_max = (size_t)64 * l.cout * 2;
+        if ((l.f.ksplit > 1 || c->padded) && (size_t)l.f.ksplit * B * l.cout * l.L > spart_max) spart_max = (size_t)l.f.ksplit * B * l.cout * l.L;
+        if (l.L < 4 && (size_t)B * l.cout * l.L > spart_max) spart_max = (size_t)B * l.cout * l.L;
+        if (i > 0 && l.d.ksplit > 1 && (size_t)l.d.ksplit * B * l.cin * l.L > spart_max) spart_max = (size_t)l.d.ksplit * B * l.cin * l.L;
+        l.z = off; off += align64((size_t)B * l.cout * l.L);
+        l.a = off; off += align64(l.cout);
+        l.s = off; off += align64(l.cout);
+        l.mean = off; off += align64(l.cout);
+        l.rstd = off; off += align64(l.cout);
+        l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
+    }
+    // the operand pass of encoder-side layer i (decimation of its producer's activation) also writes that activation at full
+    // resolution into the split input of the decoder layer that concatenates it: one read of the producer's z instead of two
+    for (int i = 0; i < c->NL; ++i) c->ly[i].skip_from = 0;
+    for (int i = 1; i <= c->n; ++i) {
+        const int dj = 2 * c->n - i + 1;
+        LayerPlan& e = c->ly[i];
+        LayerPlan& d = c->ly[dj];
+        if (e.kind == LK_DECIM && d.kind == LK_UPCAT && e.h3x && d.h3x && d.src1 == e.src0 && d.c0 % 8 == 0 && !getenv("WUNET_NO_SKIP_FUSE"))      // (test hook: the decoder-side pass reads the skip itself, eval mode's path)
+            d.skip_from = i;
+    }
+    c->stats_off = off; off += align64(stats_max);
+    c->wpkf_off = off; off += align64(wpk);
+    c->spart_off = off; off += align64(spart_max);
+    // ---- fp16-split path: split activations + forward weight packs live in the forward segment
+    size_t wfh = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        l.xh = l.xl = 0; l.h3f_wpk = l.h3d_wpk = 0;
+        if (l.h3f) {
+            const int c8 = (l.cin + 7) / 8;
+            l.xh = off; off += align64((size_t)B * c8 * l.L * 4);
+            l.xl = off; off += align64((size_t)B * c8 * l.L * 4);
+            l.h3f_wpk = wfh; wfh += (size_t)l.h3f_mtp * l.h3f_nch * l.taps * 512;
+        }
+    }
+    c->h3_wf_halfs = wfh;
+    c->h3_wf_hi = off; off += align64((wfh + 1) / 2);
+    c->h3_wf_lo = off; off += align64((wfh + 1) / 2);
+    c->fslot_off = off; off += align64((size_t)WUNET_SLOT_FLOATS * c->NL);
+    c->wmax_off = off; off += align64((size_t)WUNET_WMAX_PARTS * c->NL);
+    for (int i = 0; i < c->NL; ++i) c->ly[i].feeds_h3 = 0;
+    for (int i = 1; i < c->NL; ++i) {
+        const LayerPlan& l = c->ly[i];
+        if (!l.h3f) continue;
+        c->ly[l.src0].feeds_h3 = 1;
+        if (l.kind == LK_UPCAT) c->ly[l.src1].feeds_h3 = 1;
+    }
+    if (c->padded) {            // padded copies of the caller's tensors (rows of T floats, the caller's hold Tt)
+        c->pad_in = off; off += align64((size_t)B * T);
+        c->pad_out = off; off += align64((size_t)B * T);
+    }
+    c->fwd_floats = off;
+
+    size_t wpkb = 0, bpart_max = 0, wgpart_max = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        l.g = off; off += align64((size_t)B * l.cout * l.L);
+        l.dx = off; if (i > 0) off += align64((size_t)B * l.cin * l.L);
+        l.k1 = off; off += align64(l.cout);
+        l.k2 = off; off += align64(l.cout);
+        l.k3 = off; off += align64(l.cout);
+        l.d_wpk = wpkb;
+        if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
+        if (l.h3w) plan_h3_wgrad(l, B);
+        const size_t wg = l.h3w ? (size_t)l.h3w_ksplit * h3w_part_stride(l) : (size_t)l.w.rows * l.cout * l.cin * l.taps;
+        if (wg > wgpart_max) wgpart_max = wg;
+        long long sp = ((long long)B * l.L) / 4096;
+        l.a_split = (int)(sp < 1 ? 1 : (sp > 64 ? 64 : sp));
+        if ((size_t)l.a_split * l.cout * 2 > bpart_max) bpart_max = (size_t)l.a_split * l.cout * 2;
+    }
+    c->bpart_off = off; off += align64(bpart_max);
+    c->bmax_off = off; off += align64(bpart_max);
+    c->bound_off = off; off += align64(4096);
+    c->wgpart_off = off; off += align64(wgpart_max);
+    c->wpkb_off = off; off += align64(wpkb);
+    c->gh_off = off; off += align64((size_t)B * T);
+    {
+        long long hb = ((long long)B * T) / 2048;
+        c->head_blocks = (int)(hb < 1 ? 1 : (hb > 1024 ? 1024 : hb));
+    }
+    c->hpart_off = off; off += align64((size_t)c->head_blocks * 2);
+    c->hpart2_off = off; off += align64((size_t)64 * ci);          // pass A (head mode) partial head-weight gradients [a_split][ci]
+    // ---- fp16-split data gradient: transposed packs, one shared split g_z buffer, scale slot
+    size_t wbh = 0, gzs = 0;
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        if (!l.h3d) continue;
+        const int c8 = (l.cout + 7) / 8;
+        l.h3d_wpk = wbh; wbh += (size_t)l.h3d_mtp * l.h3d_nch * l.taps * 512;
+        l.gzh = off; off += align64((size_t)B * c8 * l.L * 4);      // per layer: the side stream reads it late
+        l.gzl = off; off += align64((size_t)B * c8 * l.L * 4);
+    }
+    c->h3_wb_halfs = wbh;
+    c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
+    c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
+    (void)gzs;
+    c->h3_slot = off; off += align64(8 + 4 * (size_t)c->NL);      // 8 zero floats (DMA zero page), then {scale, 1/scale} of g_z per layer (offset 8 + 4*layer)
+    if (c->padded) { c->pad_gout = off; off += align64((size_t)B * T); }
+    c->total_floats = off;
+}
+
+}  // namespace wunet_host
+
+using namespace wunet_host;
+
+extern "C" {
+
+const char* wunet_last_error(void) { return last_error_text(); }
+
+int wunet_create(int n_layers, int channels_interval, int batch, int length, wunet_ctx** out)
+{
+    if (!out) return fail(WUNET_E_ARG, "out is null");
+    if (n_layers < 1 || 2 * n_layers + 1 > WUNET_MAX_CONV_LAYERS) return fail(WUNET_E_ARG, "n_layers=%d unsupported (1..16)", n_layers);
+    if (channels_interval < 1 || batch < 1) return fail(WUNET_E_ARG, "bad channels_interval/batch");
+    // model/unet_basic.py:86,93 accepts any length divisible by 2^n_layers.  A length m*2^k (m odd > 1) is carried in rows padded to
+    // the next power of two: the padding holds zeros wherever a conv reads it (== the conv's own zero padding), is left out of the
+    // BatchNorm statistics and gets no gradient; the upsample uses the coordinates of the lengths that exist.
+    if (length < 4 || (length % (1 << n_layers)) != 0 || (length >> n_layers) < 1)
+        return fail(WUNET_E_ARG, "length=%d unsupported: must be >= 4 and divisible by 2^n_layers (n_layers=%d)", length, n_layers);
+    int Tp = 4;
+    while (Tp < length) Tp <<= 1;
+    const int n = n_layers, ci = channels_interval, B = batch, T = Tp;
+    if ((long long)B * (2 * n + 1) * ci * T >= (1LL << 32)) return fail(WUNET_E_ARG, "tensor too large for 32-bit offsets");
+
+    wunet_ctx* c = new wunet_ctx();
+    c->n = n; c->ci = ci; c->B = B; c->T = T; c->NL = 2 * n + 1;
+    c->Tt = length; c->padded = length != T;
+    c->ly.resize(c->NL);
+    for (int i = 0; i < c->NL; ++i) {
+        LayerPlan& l = c->ly[i];
+        if (i < n) {            // model/unet_basic.py:38-39
+            l.cin = i == 0 ? 1 : i * ci; l.cout = (i + 1) * ci; l.taps = 15; l.L = T >> i;
+            l.kind = i == 0 ? LK_RAW : LK_DECIM; l.src0 = i - 1; l.src1 = -1; l.c0 = l.cin;
+        } else if (i == n) {    // :52-57
+            l.cin = l.cout = n * ci; l.taps = 15; l.L = T >> n; l.kind = LK_DECIM; l.src0 = n - 1; l.src1 = -1; l.c0 = l.cin;
+        } else {                // :59-70
+            const int j = i - n - 1;
+            l.cout = (n - j) * ci; l.taps = 5; l.L = T >> (n - 1 - j); l.kind = LK_UPCAT;
+            l.src0 = i - 1; l.src1 = n - 1 - j;
+            l.c0 = c->ly[i - 1].cout;
+            l.cin = l.c0 + c->ly[l.src1].cout;
+        }
+        l.logL = ilog2(l.L);
+        l.Lt = (int)(((long long)l.L * length) / T);       // (T / L is the level's decimation factor, a power of two dividing length)
+    }
+    layout_workspace(c);
+    *out = c;
+    return WUNET_OK;
+}
+
+int wunet_set_h3(wunet_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(WUNET_E_ARG, "null ctx");
+    // 3 / 4: the planner's (3) or the forced (4) layer set on the bf16 mode of the same kernels
+    ctx->bf = (enable == 3 || enable == 4) ? 1 : 0;
+    ctx->h3 = (enable == 2 || enable == 4) ? 2 : (enable ? 1 : 0);
+    layout_workspace(ctx);          // sizes and offsets change: call before wunet_workspace_bytes
+    return WUNET_OK;
+}
+
+void wunet_destroy(wunet_ctx* ctx)
+{
+    if (!ctx) return;
+    for (auto& kv : ctx->side) {
+        hipStreamDestroy(kv.second.stream); hipEventDestroy(kv.second.ev_fork); hipEventDestroy(kv.second.ev_join); hipEventDestroy(kv.second.ev_pack);
+        hipEventDestroy(kv.second.ev_fpack); hipEventDestroy(kv.second.ev_fpack2);
+    }
+    delete ctx;
+}
+
+size_t wunet_workspace_bytes(const wunet_ctx* ctx, int with_backward)
+{
+    if (!ctx) return 0;
+    return (with_backward ? ctx->total_floats : ctx->fwd_floats) * sizeof(float);
+}
+
+int wunet_num_conv_layers(const wunet_ctx* ctx) { return ctx ? ctx->NL : 0; }
+
+int wunet_layer_info(const wunet_ctx* ctx, int layer, size_t* z_offset_floats, int* channels, int* length)
+{
+    if (!ctx || layer < 0 || layer >= ctx->NL) return fail(WUNET_E_ARG, "bad layer");
+    if (z_offset_floats) *z_offset_floats = ctx->ly[layer].z;
+    if (channels) *channels = ctx->ly[layer].cout;
+    if (length) *length = ctx->ly[layer].L;
+    return WUNET_OK;
+}
+
+}  // extern "C"

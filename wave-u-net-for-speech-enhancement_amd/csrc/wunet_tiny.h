@@ -6,7 +6,7 @@
 #include "wunet_elementwise.h"
 
 // conv input (see prep_decim_kernel / prep_upcat_kernel), one thread per element
-__global__ __launch_bounds__(WUNET_THREADS) void prep_scalar_kernel(PrepArgs A, int upcat)
+static __global__ __launch_bounds__(WUNET_THREADS) void prep_scalar_kernel(PrepArgs A, int upcat)
 {
     const int C = A.C0 + A.C1;
     const size_t total = (size_t)A.B * C * A.L;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_scalar_kernel(PassAArgs 
     }
 }
 
-__global__ __launch_bounds__(WUNET_THREADS) void gz_scalar_kernel(const float* g, const float* z, const float* k1, const float* k2,
+static __global__ __launch_bounds__(WUNET_THREADS) void gz_scalar_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                    const float* k3, int C, int logL, size_t n, float* gz)
 {
     for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS) {
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_scalar_kernel(const float* g
 
 // out[b,r,l] = sum_{c,k} W(r,c,k) * x[b,c,l+k-pad];  forward: W = w[r][c][k] (w = [R][C][K]);
 // data gradient (transposed): W = w[c][r][K-1-k] (w = [C][R][K]).  No bias.
-__global__ __launch_bounds__(WUNET_THREADS) void tiny_conv_kernel(const float* x, const float* w, float* out, int B, int C, int R,
+static __global__ __launch_bounds__(WUNET_THREADS) void tiny_conv_kernel(const float* x, const float* w, float* out, int B, int C, int R,
                                                                    int L, int logL, int K, int transposed)
 {
     const int pad = K / 2;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void tiny_conv_kernel(const float* x
 }
 
 // dw[co][ci][k] = sum_{b,l} g[b,co,l] * x[b,ci,l+k-pad]
-__global__ __launch_bounds__(WUNET_THREADS) void tiny_wgrad_kernel(const float* g, const float* x, float* dw, int B, int Cin, int Cout,
+static __global__ __launch_bounds__(WUNET_THREADS) void tiny_wgrad_kernel(const float* g, const float* x, float* dw, int B, int Cin, int Cout,
                                                                     int L, int K)
 {
     const int pad = K / 2;

@@ -43,21 +43,32 @@ class Engine:
     MAX_CONTEXTS = 32
 
     def _ctx_for(self, n_layers, ci, batch, length, device=None):
+        """The context of one (shape, device), created on first use.  Every C call that takes the handle runs inside
+        `with self._using(...) as h` (below): a handle that some thread still holds is never destroyed by the eviction of
+        another thread (stock nn.DataParallel calls forward from one thread per replica, trainer/base_trainer.py:26-27)."""
         key = (n_layers, ci, batch, length, str(device))
         with self._lock:
-            h = self._ctx.get(key)
-            if h is None:
+            ent = self._ctx.get(key)
+            if ent is None:
                 h = ctypes.c_void_p()
                 self._check(self.lib.wunet_create(n_layers, ci, batch, length, ctypes.byref(h)))
                 if self.h3:
                     self._check(self.lib.wunet_set_h3(h, self.h3))
-                self._ctx[key] = h
-                while len(self._ctx) > self.MAX_CONTEXTS:
-                    _, old = self._ctx.popitem(last=False)
-                    self.lib.wunet_destroy(old)      # (HIP defers the side stream's destruction until its work has drained)
+                ent = self._ctx[key] = [h, 0]                    # [handle, holders]
             else:
                 self._ctx.move_to_end(key)
-        return h
+            ent[1] += 1
+            # least-recently-used contexts nobody holds go beyond MAX_CONTEXTS (oldest first; the one just handed out is held)
+            for k in [k for k, e in self._ctx.items() if e[1] == 0][:max(0, len(self._ctx) - self.MAX_CONTEXTS)]:
+                self.lib.wunet_destroy(self._ctx.pop(k)[0])       # (HIP defers the side stream's destruction until its work has drained)
+        return key, ent
+
+    def _release(self, ent):
+        with self._lock:
+            ent[1] -= 1
+
+    def _using(self, n_layers, ci, batch, length, device=None):
+        return _CtxHold(self, *self._ctx_for(n_layers, ci, batch, length, device))
 
     def _require(self, t, name):
         if t.dtype != torch.float32 and t.dtype != torch.int64:
@@ -96,11 +107,10 @@ class Engine:
         for t in list(running) + list(nbt):
             self._require(t, "buffer")
         B, _, T = noisy.shape
-        h = self._ctx_for(n_layers, ci, B, T, noisy.device)
-        nbytes = self.lib.wunet_workspace_bytes(h, 1 if with_backward else 0)
-        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=noisy.device)
-        out = torch.empty_like(noisy)
-        with self._device_guard(noisy.device):
+        with self._using(n_layers, ci, B, T, noisy.device) as h, self._device_guard(noisy.device):
+            nbytes = self.lib.wunet_workspace_bytes(h, 1 if with_backward else 0)
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=noisy.device)
+            out = torch.empty_like(noisy)
             self._check(self.lib.wunet_forward(h, noisy.data_ptr(), self._ptrs(params), self._ptrs(running),
                                                self._ptrs(nbt), 1 if training else 0, 1 if with_backward else 0, ws.data_ptr(),
                                                out.data_ptr(), self._stream(noisy.device)))
@@ -110,27 +120,25 @@ class Engine:
         """join=False: the caller's stream does not wait for the range's weight gradients (side stream); make a stream see them
         with `join_weight_gradients` (parallel.GradSync does, on the stream that launches the bucket's all-reduce)."""
         B, _, T = noisy.shape
-        h = self._ctx_for(n_layers, ci, B, T, noisy.device)
         self._require(grad_enhanced, "grad_output")
         nl = 2 * n_layers + 1
         lb, le = layer_range if layer_range is not None else (0, nl)
         fn = self.lib.wunet_backward_range if join else self.lib.wunet_backward_range_async
-        with self._device_guard(noisy.device):
+        with self._using(n_layers, ci, B, T, noisy.device) as h, self._device_guard(noisy.device):
             self._check(fn(h, noisy.data_ptr(), self._ptrs(params), enhanced.data_ptr(), grad_enhanced.data_ptr(), ws.data_ptr(),
                            self._ptrs(grads), lb, le, self._stream(noisy.device)))
 
     def join_weight_gradients(self, n_layers, ci, noisy):
         """Torch's current stream waits for everything the weight-gradient side stream has been given so far."""
         B, _, T = noisy.shape
-        h = self._ctx_for(n_layers, ci, B, T, noisy.device)
-        with self._device_guard(noisy.device):
+        with self._using(n_layers, ci, B, T, noisy.device) as h, self._device_guard(noisy.device):
             self._check(self.lib.wunet_backward_join(h, self._stream(noisy.device)))
 
     def layer_output(self, n_layers, ci, batch, length, ws, layer):
         """Raw conv output (pre-BatchNorm) of conv layer `layer` as a view into a workspace (tests/profiling)."""
-        h = self._ctx_for(n_layers, ci, batch, length, ws.device)
         off, ch, ln = ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
-        self._check(self.lib.wunet_layer_info(h, layer, ctypes.byref(off), ctypes.byref(ch), ctypes.byref(ln)))
+        with self._using(n_layers, ci, batch, length, ws.device) as h:
+            self._check(self.lib.wunet_layer_info(h, layer, ctypes.byref(off), ctypes.byref(ch), ctypes.byref(ln)))
         return ws[off.value: off.value + batch * ch.value * ln.value].view(batch, ch.value, ln.value)
 
     # ------------------------------------------------------------------ losses
@@ -174,6 +182,20 @@ def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, 
 
 
 Engine.adam_step = _adam_step
+
+
+class _CtxHold:
+    """`with engine._using(shape...) as handle`: the context cannot be evicted while the block runs."""
+
+    def __init__(self, engine, key, ent):
+        self.engine, self.key, self.ent = engine, key, ent
+
+    def __enter__(self):
+        return self.ent[0]
+
+    def __exit__(self, *a):
+        self.engine._release(self.ent)
+        return False
 
 
 class _NullCtx:

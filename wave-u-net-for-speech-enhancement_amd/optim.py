@@ -31,6 +31,11 @@ class FusedAdam(torch.optim.Optimizer):
         self.device_step = device_step
         self._dev = {}            # group index -> (int64 step counter, 2-float hyper buffer) on the parameters' device
 
+    def hyper_signature(self):
+        """Everything a captured step() bakes into its kernel arguments (lr, betas, eps per group, grad_scale): a driver that
+        replays a graph compares it with the signature at capture time and re-captures when it changed (trainer.Trainer._step)."""
+        return tuple((g["lr"], tuple(g["betas"]), g["eps"]) for g in self.param_groups) + (self.grad_scale,)
+
     def _engine(self):
         return self._engine_override if self._engine_override is not None else default_engine()
 
@@ -43,6 +48,14 @@ class FusedAdam(torch.optim.Optimizer):
         for g in self.param_groups:
             for k, v in _ADAM_DEFAULTS.items():
                 g.setdefault(k, v)
+        # "step" as this class keeps it: a float32 scalar on the HOST.  A checkpoint loaded with map_location=<gpu>
+        # (trainer.Trainer._resume_checkpoint, the reference's base_trainer.py:70-74) leaves it on the device - step() would then
+        # synchronise once per parameter and abort a graph capture - and the torch 1.2 the reference was tested with stored a
+        # Python int (README.md:27).
+        for st in self.state.values():
+            if "step" in st:
+                v = st["step"]
+                st["step"] = torch.tensor(float(v.item() if torch.is_tensor(v) else v), dtype=torch.float32, device="cpu")
         self._dev = {}            # re-seeded from the loaded host step at the next step()
 
     def advance_host_step(self, n=1):

@@ -66,6 +66,7 @@ class Trainer:
         if self.use_graph:
             optimizer.device_step = True
         self._graph = None
+        self._graph_sig = None
         self._static = None
         self._eager_steps = 0
         self.start_epoch = 1
@@ -91,10 +92,16 @@ class Trainer:
             raise ValueError(f"batch_size={loader.batch_size} (the global batch, as nn.DataParallel would split it) must be a "
                              f"multiple of the world size {self.world}")
         shuffle = isinstance(loader.sampler, torch.utils.data.RandomSampler)
-        sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.rank, shuffle=shuffle, drop_last=True)
+        # the reference's loader (train.py:15-21) keeps a ragged last batch: so does every rank here (the sampler pads the
+        # dataset to equal per-rank counts instead of dropping items), and the loader's own options travel along
+        sampler = DistributedSampler(loader.dataset, num_replicas=self.world, rank=self.rank, shuffle=shuffle, drop_last=False)
+        extra = {}
+        if loader.num_workers > 0:
+            extra = dict(persistent_workers=loader.persistent_workers, prefetch_factor=loader.prefetch_factor)
         return DataLoader(loader.dataset, batch_size=loader.batch_size // self.world, sampler=sampler,
-                          num_workers=loader.num_workers, pin_memory=loader.pin_memory, drop_last=True,
-                          collate_fn=loader.collate_fn)
+                          num_workers=loader.num_workers, pin_memory=loader.pin_memory, drop_last=loader.drop_last,
+                          collate_fn=loader.collate_fn, worker_init_fn=loader.worker_init_fn, generator=loader.generator,
+                          timeout=loader.timeout, **extra)
 
     # ---- checkpoints: reference layout (base_trainer.py:62-124)
     def _resume_checkpoint(self):
@@ -137,12 +144,17 @@ class Trainer:
             self.optimizer.step()               # (host side of step(): state["step"] += 1 happened once, here)
             self._static_loss = loss.detach()
         self._graph = graph
+        self._graph_sig = self.optimizer.hyper_signature()
         # capture does not execute: undo the host-side count of the captured call; every replay counts itself
         self.optimizer.advance_host_step(-1)
 
     def _step(self, mixture, clean):
         if not self.use_graph:
             return self._eager_step(mixture, clean)
+        if self._graph is not None and self.optimizer.hyper_signature() != self._graph_sig:
+            # lr / betas / eps / grad_scale are kernel arguments of the captured Adam step: a scheduler, a manual decay or a
+            # load_state_dict with another lr would be ignored by the replay - capture again with the new values
+            self._graph = None
         if self._graph is None:
             if self._eager_steps < GRAPH_WARMUP_STEPS:
                 self._eager_steps += 1
