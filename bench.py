@@ -66,9 +66,10 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
-def load_pmc_traffic():
+def load_pmc_traffic(section=None):
     """HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside the bench): profiles/pmc_traffic.json,
-    produced by tools/measure_round.sh + tools/collect_round.py, stamped with the source hash of the build it was measured on."""
+    produced by tools/measure_round.sh + tools/collect_round.py, stamped with the source hash of the build it was measured on.
+    section: None = the headline workload; "gemm_fp32" / "deep16_bf16" = the PMC passes of the extras (same file, own sub-object)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         pmc = json.load(open(path))
@@ -77,9 +78,89 @@ def load_pmc_traffic():
     if pmc.get("source_hash") != source_hash():
         return {"kernels": None, "why": f"profiles/pmc_traffic.json is stale (measured on sources {pmc.get('source_hash')}, these are "
                                         f"{source_hash()}): refused"}
+    if section is not None:
+        sub = (pmc.get("sections") or {}).get(section)
+        if sub is None:
+            return {"kernels": None, "why": f"profiles/pmc_traffic.json holds no PMC pass of '{section}'"}
+        pmc = dict(sub)
     pmc["why"] = ("profiles/pmc_traffic.json (rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, FETCH "
                   "doubled per the gfx950 note of MI355X_MICROARCH.md; measured on these sources)")
     return pmc
+
+
+def kernel_rows(lib, fn, nprof):
+    """Per-kernel durations of `nprof` calls of fn: HIP events recorded by the library on the launch stream around every kernel it
+    annotates (events perturb the launch stream slightly, so headline values are taken without them)."""
+    lib.wunet_profile_enable(1)
+    for _ in range(nprof):
+        fn()
+    buf = ctypes.create_string_buffer(1 << 16)
+    lib.wunet_profile_collect(buf, len(buf))
+    lib.wunet_profile_enable(0)
+    rows = []
+    for line in buf.value.decode().strip().splitlines():
+        name, n, ms, fl, by = line.split("\t")
+        rows.append({"kernel": name, "launches": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
+    rows.sort(key=lambda r: -r["ms"])
+    return rows
+
+
+def gemm_peak(kernel):
+    if "bf16" in kernel:
+        return PEAK_F16_MFMA_TFLOPS, "2500 TFLOP/s dense bf16 MFMA"
+    if "_h3" in kernel:
+        return PEAK_SPLIT_TFLOPS, "2500 TFLOP/s dense f16 MFMA / 3 passes per fp32-equivalent product"
+    return PEAK_FP32_MFMA_TFLOPS, "fp32 MFMA (v_mfma_f32_16x16x4_f32)"
+
+
+def roofline_of(rows, nprof, pmc, step_algorithmic_bytes):
+    """The roofline object of the contract for the GEMM kernel that takes the most time in `rows` (+ the HBM-side view of the same
+    kernel, the other GEMM kernels, the HBM-bound kernels and the whole-step traffic from the PMC file)."""
+    gemm_rows = [r for r in rows if r["flops"] > 0 and ("mfma" in r["kernel"] or "_h3" in r["kernel"])]
+    mem_rows = [r for r in rows if r not in gemm_rows]
+    if not gemm_rows:
+        return None
+    top = gemm_rows[0]
+    avg_ms = top["ms"] / top["launches"]
+    achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
+    mfma_ms = sum(r["ms"] for r in gemm_rows) / nprof
+    traffic, traffic_src = None, pmc["why"]
+    if pmc["kernels"] is not None and top["kernel"] in pmc["kernels"]:
+        traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
+    peak, peak_note = gemm_peak(top["kernel"])
+    # the HBM-bound kernels of the shallow levels (north_star: "rocprof-reported HBM GB/s for the memory-bound shallow
+    # levels"): algorithmic bytes / HIP-event time, same pass
+    groups = {}
+    for r in mem_rows:
+        key = r["kernel"].split("<")[0]
+        g = groups.setdefault(key, {"kernel": key, "ms": 0.0, "bytes": 0.0, "launches": 0})
+        g["ms"] += r["ms"]; g["bytes"] += r["bytes"]; g["launches"] += r["launches"]
+    memory_bound = [{"kernel": g["kernel"], "launches_per_step": g["launches"] / nprof, "ms_per_step": g["ms"] / nprof,
+                     "algorithmic_GBps": g["bytes"] / (g["ms"] * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
+                    for g in sorted(groups.values(), key=lambda g: -g["ms"]) if g["ms"] > 0]
+    whole = None
+    if pmc["kernels"] is not None and pmc.get("whole_step_bytes"):
+        whole = {"hbm_bytes_per_step": pmc["whole_step_bytes"], "algorithmic_bytes_per_step": step_algorithmic_bytes,
+                 "ratio": pmc["whole_step_bytes"] / step_algorithmic_bytes}
+    return {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": peak, "peak_note": peak_note,
+            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+            "traffic_whole_step": whole,
+            "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
+            # the same kernel against the other roof: its algorithmic bytes / time, and where it sits relative to the ridge
+            "algorithmic_GBps": top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "intensity_flop_per_byte": top["flops"] / max(top["bytes"], 1.0),
+            "ridge_flop_per_byte": peak * 1e12 / (PEAK_HBM_GBS * 1e9),
+            "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
+            "mfma_kernels_ms_per_step": mfma_ms,
+            "all_mfma_kernels_achieved": sum(r["flops"] for r in gemm_rows) / nprof / (mfma_ms * 1e-3) / 1e12,
+            "top5": [{"kernel": r["kernel"], "ms_per_step": r["ms"] / nprof,
+                      "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12} for r in gemm_rows[:(999 if os.environ.get("WUNET_BENCH_ALL") else 5)]],
+            "memory_bound_kernels": memory_bound,
+            "memory_bound_ms_per_step": sum(m["ms_per_step"] for m in memory_bound),
+            "kernels_timed_per_step": sum(r["launches"] for r in rows) / nprof}
 
 
 def timed(fn, warmup, steps, batch, what):
@@ -303,69 +384,15 @@ def main():
         for _ in range(nprof):          # keep the collectives of the profiled pass matched on every rank
             eager_step()
     if rank == 0 and not args.no_roofline:
-        # per-kernel durations: HIP events recorded by the library on the launch stream around every MFMA
-        # kernel, over a second pass of the same steps (events perturb the launch stream slightly, so the
-        # headline value above is taken without them)
+        # per-kernel durations over a second pass of the same steps (the per-kernel events need eager launches: a captured graph
+        # cannot be instrumented)
         lib = engine_mod.default_engine().lib
-        lib.wunet_profile_enable(1)
-        for _ in range(nprof):
-            eager_step()                 # (the per-kernel events need eager launches: a captured graph cannot be instrumented)
-        buf = ctypes.create_string_buffer(1 << 16)
-        lib.wunet_profile_collect(buf, len(buf))
-        lib.wunet_profile_enable(0)
-        rows = []
-        for line in buf.value.decode().strip().splitlines():
-            name, n, ms, fl, by = line.split("\t")
-            rows.append({"kernel": name, "launches": int(n), "ms": float(ms), "flops": float(fl), "bytes": float(by)})
-        rows.sort(key=lambda r: -r["ms"])
-        gemm_rows = [r for r in rows if r["flops"] > 0 and ("mfma" in r["kernel"] or "_h3" in r["kernel"])]
-        mem_rows = [r for r in rows if r not in gemm_rows]
-        if gemm_rows:
-            top = gemm_rows[0]
-            avg_ms = top["ms"] / top["launches"]
-            achieved = top["flops"] / top["launches"] / (avg_ms * 1e-3) / 1e12
-            mfma_ms = sum(r["ms"] for r in gemm_rows) / nprof
-            pmc = load_pmc_traffic()
-            traffic, traffic_src = None, pmc["why"]
-            if pmc["kernels"] is not None and top["kernel"] in pmc["kernels"]:
-                traffic = pmc["kernels"][top["kernel"]]["hbm_bytes_per_launch"]
-            is_split = "_h3" in top["kernel"]
-            is_bf = "bf16" in top["kernel"]
-            peak = PEAK_F16_MFMA_TFLOPS if is_bf else PEAK_SPLIT_TFLOPS if is_split else PEAK_FP32_MFMA_TFLOPS
-            # the HBM-bound kernels of the shallow levels (north_star: "rocprof-reported HBM GB/s for the memory-bound shallow
-            # levels"): algorithmic bytes / HIP-event time, same pass
-            groups = {}
-            for r in mem_rows:
-                key = r["kernel"].split("<")[0]
-                g = groups.setdefault(key, {"kernel": key, "ms": 0.0, "bytes": 0.0, "launches": 0})
-                g["ms"] += r["ms"]; g["bytes"] += r["bytes"]; g["launches"] += r["launches"]
-            memory_bound = [{"kernel": g["kernel"], "launches_per_step": g["launches"] / nprof, "ms_per_step": g["ms"] / nprof,
-                             "algorithmic_GBps": g["bytes"] / (g["ms"] * 1e-3) / 1e9,
-                             "frac_of_hbm_peak": g["bytes"] / (g["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS}
-                            for g in sorted(groups.values(), key=lambda g: -g["ms"]) if g["ms"] > 0]
-            whole = None
-            if pmc["kernels"] is not None and pmc.get("whole_step_bytes"):
-                whole = {"hbm_bytes_per_step": pmc["whole_step_bytes"], "algorithmic_bytes_per_step": args.batch * step_bytes,
-                         "ratio": pmc["whole_step_bytes"] / (args.batch * step_bytes)}
-            roofline = {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": peak,
-                        "peak_note": ("2500 TFLOP/s dense bf16 MFMA" if is_bf else "2500 TFLOP/s dense f16 MFMA / 3 passes per fp32-equivalent product" if is_split
-                                      else "fp32 MFMA (v_mfma_f32_16x16x4_f32)"),
-                        "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-                        "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                        "traffic_whole_step": whole,
-                        "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
-                        # the same kernel against the other roof: its algorithmic bytes / time, and where it sits relative to the ridge
-                        "algorithmic_GBps": top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9,
-                        "frac_of_hbm_peak": top["bytes"] / top["launches"] / (avg_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                        "intensity_flop_per_byte": top["flops"] / max(top["bytes"], 1.0),
-                        "ridge_flop_per_byte": peak * 1e12 / (PEAK_HBM_GBS * 1e9),
-                        "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
-                        "mfma_kernels_ms_per_step": mfma_ms,
-                        "all_mfma_kernels_achieved": sum(r["flops"] for r in gemm_rows) / nprof / (mfma_ms * 1e-3) / 1e12,
-                        "top5": [{"kernel": r["kernel"], "ms_per_step": r["ms"] / nprof,
-                                  "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12} for r in gemm_rows[:(999 if os.environ.get("WUNET_BENCH_ALL") else 5)]],
-                        "memory_bound_kernels": memory_bound,
-                        "memory_bound_ms_per_step": sum(m["ms_per_step"] for m in memory_bound)}
+        rows = kernel_rows(lib, eager_step, nprof)
+        deep16 = args.layers == 16 and args.frame == 65536 and args.batch == 32
+        section = ("train" if default_net and args.batch == 64 and split_gemm and not bf16_gemm else
+                   "gemm_fp32" if default_net and args.batch == 64 and not split_gemm else
+                   "deep16_bf16" if deep16 and bf16_gemm else "-") if args.mode == "train" else "-"
+        roofline = roofline_of(rows, nprof, load_pmc_traffic(None if section == "train" else section), args.batch * step_bytes)
 
     # ---- extras the driver should see next to the headline (same box, same process): the exact-fp32 arithmetic and the
     #      eval-mode forward (BASELINE configs[1])
@@ -384,7 +411,43 @@ def main():
             c32(clean, m32(noisy)).backward()
             o32.step()
         extras["gemm_fp32"] = timed(step32, 3, 10, args.batch, "training step, every GEMM on v_mfma_f32_16x16x4_f32 (exact fp32: WUNET_H3=0)")
-        del m32, o32
+        extras["gemm_fp32"]["dtype"] = "f32"
+        if not args.no_roofline:
+            # the strictly-fp32 figure carries its own roofline: dominant v_mfma_f32_16x16x4_f32 kernel against the 157.3 TF fp32 peak
+            extras["gemm_fp32"]["roofline"] = roofline_of(kernel_rows(m32._engine_override.lib, step32, 3), 3, load_pmc_traffic("gemm_fp32"),
+                                                          args.batch * step_bytes)
+        del m32, o32, c32
+        torch.cuda.empty_cache()
+        # BASELINE.json configs[4]: "24-level / 65536-sample deep variant, bf16, batch=32" - 16 levels is the deepest net that exists
+        # at 65536 samples: bf16 operands, one bf16 MFMA pass, f32 accumulation / BatchNorm / gradients
+        try:
+            torch.manual_seed(0)
+            e16 = engine_mod.Engine(h3=3)
+            m16 = pkg.Model(n_layers=16, channels_interval=CI).to(device).train()
+            m16._engine_override = e16
+            c16 = pkg.smooth_l1_loss()
+            c16._engine_override = e16
+            o16 = adam_cls(m16.parameters(), lr=1e-3, betas=(0.9, 0.999))
+            n16, cl16 = synthetic_batch(32, device, seed=rank, frame=65536)
+
+            def step16():
+                o16.zero_grad(set_to_none=True)
+                c16(cl16, m16(n16)).backward()
+                o16.step()
+            d16 = timed(step16, 3, 10, 32, "training step of the 16-level / 65536-sample net at batch 32, bf16 GEMM operands (WUNET_H3=3): BASELINE.json "
+                                            "configs[4] (24 levels do not exist at 65536 samples, SURVEY.md section 0); outside the 1e-4 fp32 parity bar, "
+                                            "checked against the reference under bf16 autocast (tests/test_gpu_parity.py)")
+            d16["value"], d16["unit"] = d16["frames_per_s"], "65536-sample frames/s"
+            d16["dtype"] = "bf16 operands, f32 accumulate / BatchNorm / gradients"
+            f16fl, f16by = net_flops_bytes(16, CI, 65536)
+            d16["whole_step_tflops"] = d16["frames_per_s"] * (3.0 * f16fl - 2.0 * CI * 15 * 65536) / 1e12
+            if not args.no_roofline:
+                d16["roofline"] = roofline_of(kernel_rows(e16.lib, step16, 3), 3, load_pmc_traffic("deep16_bf16"), 32 * 3.0 * f16by)
+            extras["deep16_bf16"] = d16
+            del m16, o16, c16, n16, cl16
+            torch.cuda.empty_cache()
+        except Exception as e:      # (an extra must never take the headline line down with it)
+            extras["deep16_bf16"] = {"error": f"{type(e).__name__}: {e}"}
         model.eval()
 
         def fwd():
@@ -408,7 +471,8 @@ def main():
                        else "16384-sample frames/sec eval forward only, 12-level Wave-U-Net (extra, BASELINE configs[1])")
                       if default_net else f"{args.frame}-sample frames/sec, {args.layers}-level Wave-U-Net, mode={args.mode} (extra)",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "ms_per_step_median": median_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "ms_per_step_median": median_ms,
+            "value_at_median": (args.batch * world / (median_ms * 1e-3)) if median_ms else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("bf16 operands, f32 accumulate / BatchNorm / gradients (levels >= 16 samples: 1 x bf16 MFMA; the rest f32 MFMA)" if bf16_gemm
                       else "f32 (levels >= 16 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
                       else "f32"),
@@ -419,7 +483,9 @@ def main():
                        "global_batch": args.batch * world, "frame": args.frame,
                        "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
             "whole_step_tflops_per_gpu": per_gpu_fps * step_flop / 1e12,
-            "whole_step_frac_of_fp32_peak": per_gpu_fps * step_flop / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            # against the roof of the arithmetic that ran: 2500 / 3 TF for the fp16-split GEMMs, 2500 TF bf16, 157.3 TF exact fp32
+            "whole_step_frac_of_gemm_peak": per_gpu_fps * step_flop / 1e12 / (PEAK_F16_MFMA_TFLOPS if bf16_gemm else PEAK_SPLIT_TFLOPS if split_gemm
+                                                                                else PEAK_FP32_MFMA_TFLOPS),
             "gemm": "bf16" if bf16_gemm else "split" if split_gemm else "fp32",
             "whole_step_algorithmic_hbm_frac": per_gpu_fps * step_bytes / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,

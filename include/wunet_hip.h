@@ -128,6 +128,22 @@ int wunet_num_conv_layers(const wunet_ctx* ctx);
 int wunet_profile_enable(int on);
 long long wunet_profile_collect(char* buf, size_t cap);
 
+/* ---- data-parallel exchange: the flat fp32 gradient buffer summed over the GPUs of the job by RCCL.
+ * Replaces what `torch.nn.DataParallel(model, device_ids=...)` does implicitly per step - replicate / scatter / gather and the
+ * reduce-add of the replicas' gradients onto device 0 (/root/reference/trainer/base_trainer.py:26-27) - with ONE process per GPU
+ * and an all-reduce (sum) over xGMI; the caller scales by 1/world (or leaves it to wunet_adam_step's grad_scale).
+ * wunet_comm_unique_id: rank 0 draws the 128-byte RCCL id; the caller carries it to the other ranks (any side channel: a file, a
+ * socket, torch.distributed's store).  wunet_comm_create: collective over all `world` ranks, on the calling thread's current device.
+ * wunet_comm_allreduce_sum: in place over buf[0 .. count), enqueued on `stream` like a kernel: it orders with the backward's kernels
+ * on that stream and can be captured into the step's hipGraph.  World size 1 needs no RCCL (the sum over one rank is a no-op). */
+#define WUNET_COMM_ID_BYTES 128
+typedef struct wunet_comm wunet_comm;
+int wunet_comm_unique_id(unsigned char* id /* [WUNET_COMM_ID_BYTES] */);
+int wunet_comm_create(const unsigned char* id, int world, int rank, wunet_comm** out);
+int wunet_comm_allreduce_sum(wunet_comm* comm, float* buf, size_t count, void* stream);
+int wunet_comm_world(const wunet_comm* comm);
+void wunet_comm_destroy(wunet_comm* comm);
+
 /* SURVEY.md section 8 (f4), the data input path.  Replaces, for a whole batch and on the device, the reference's per-item aligned
  * random crop - `sample_fixed_length_data_aligned(mixture, clean, sample_length)`, /root/reference/util/utils.py:101-113, called from
  * `Dataset.__getitem__`, dataset/waveform_dataset.py:56-67 - and the collate of train.py:15-21: window b of BOTH outputs is

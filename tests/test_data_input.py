@@ -89,12 +89,27 @@ def test_dataset_matches_reference_semantics(wd, tmp_path):
         wd.Dataset(str(lst), sample_length=100000)[0]                      # shorter than sample_length: the reference asserts too
 
 
-def test_shard_loader_crops_on_device(wd, tmp_path):
+def _emu_engine():
+    import importlib
+    import emu_lib
+    from conftest import PKG_NAME
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    return eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+
+
+@pytest.mark.parametrize("through_kernel", [False, True], ids=["host-slices", "crop-kernel"])
+def test_shard_loader_crops_on_device(wd, tmp_path, through_kernel):
+    """Every window of a batch is a window of the item it names, mixture and clean cut at the SAME start - the reference's
+    sample_fixed_length_data_aligned (util/utils.py:101-113) - checked against the corpus as written, not against the loader.
+    through_kernel: the batch is cut by crop_windows_kernel behind wunet_crop_windows (the GPU loader's path), run here on the
+    emulator build of the same kernel source."""
     lst, items = _corpus(tmp_path, n=6, seed=3)
     prefix = str(tmp_path / "shard")
     assert wd.pack_shard(str(lst), prefix) == 6
     L = 320
-    loader = wd.ShardLoader(prefix, batch_size=4, sample_length=L, device="cpu", seed=11, steps_per_epoch=3)
+    eng = _emu_engine() if through_kernel else None
+    loader = wd.ShardLoader(prefix, batch_size=4, sample_length=L, device="cpu", seed=11, steps_per_epoch=3, engine=eng)
     by_name = {nm: (noisy, clean) for noisy, clean, nm in items}
     seen = 0
     for mixture, clean, names in loader:
@@ -108,8 +123,22 @@ def test_shard_loader_crops_on_device(wd, tmp_path):
             assert np.array_equal(clean[b, 0].numpy(), clean_src[hits[0]:hits[0] + L])       # aligned with the mixture
         seen += 1
     assert seen == len(loader) == 3
-    again = wd.ShardLoader(prefix, batch_size=4, sample_length=L, device="cpu", seed=11, steps_per_epoch=1)
+    again = wd.ShardLoader(prefix, batch_size=4, sample_length=L, device="cpu", seed=11, steps_per_epoch=1, engine=eng)
     first = next(iter(wd.ShardLoader(prefix, batch_size=4, sample_length=L, device="cpu", seed=11, steps_per_epoch=1)))
-    assert torch.equal(next(iter(again))[0], first[0])                     # seeded: reproducible
+    assert torch.equal(next(iter(again))[0], first[0])                     # seeded: reproducible, and both paths cut the same windows
     with pytest.raises(ValueError):
         wd.ShardLoader(prefix, batch_size=2, sample_length=100000)
+
+
+def test_crop_kernel_edges(wd):
+    """wunet_crop_windows on the emulator: ragged row length (not a multiple of 4: the scalar tail), a window at the very end of the
+    shard, starts outside the shard clamped instead of read."""
+    eng = _emu_engine()
+    total, L, B = 1000, 37, 5
+    flat_m = torch.arange(total, dtype=torch.float32)
+    flat_c = -torch.arange(total, dtype=torch.float32)
+    starts = torch.tensor([0, 1, total - L, total + 50, -7], dtype=torch.int64)
+    mix, cl = torch.empty(B, 1, L), torch.empty(B, 1, L)
+    eng.crop_windows(flat_m, flat_c, starts, mix, cl)
+    for b, s0 in enumerate([0, 1, total - L, total - L, 0]):
+        assert torch.equal(mix[b, 0], flat_m[s0:s0 + L]) and torch.equal(cl[b, 0], flat_c[s0:s0 + L]), b

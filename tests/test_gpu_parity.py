@@ -199,19 +199,22 @@ def test_full_size_properties(pkg, dev):
     l2.backward()
     assert (out.detach().cpu() - o2.detach()).abs().max().item() < TOL
     assert abs(lv.item() - l2.item()) < 1e-5
-    # the same step on the exact-fp32 MFMA kernels: the reference here is ATen's fp32 CPU path, whose own rounding noise is
-    # 1e-3 of the norm of the smallest gradient tensors (encoder.3 weight: |g| ~ 1e-6 after 20 BatchNorm-backward passes), so
-    # the relative bar is 1e-3 or 3x what the fp32 kernels get against the same reference, whichever is larger
-    m0, _, _ = _run_model(pkg, dev, n, ci, noisy, clean, "smooth_l1", h3=0)
-    g0 = dict(m0.named_parameters())
+    # Gradient bar at this size, derived from profiles/r3_gradient_noise_b64.txt (tools/diag_gemm_ref.py --batch 64 --seeds 0 1 2: the
+    # worst tensor-relative distance over all gradient tensors and three input seeds): the reference's own fp32 CPU arithmetic sits
+    # 3.3e-3 from a float64 run of the same step, the exact-fp32 MFMA kernels 7.9e-3, the split kernels 7.8e-3 (8.2e-3 / 7.9e-3 from
+    # the reference itself) - 25 BatchNorm-backward passes amplify fp32 rounding to that level on the smallest tensors whichever
+    # arithmetic runs, while the absolute error stays at 3e-6 (bar 1e-4).  The relative bar is 2.5 x the measured worst case.
+    REL_BAR = 2.0e-2
+    worst_rel = 0.0
     for k, p in m.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("out"):
             continue
         ref = tsd[k].grad
         err = (p.grad.cpu() - ref).abs().max().item()
         rel = ((p.grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
-        rel0 = ((g0[k].grad.cpu() - ref).norm() / (ref.norm() + 1e-12)).item()
-        assert err < TOL and rel < max(1e-3, 3 * rel0), (k, err, rel, rel0)
+        worst_rel = max(worst_rel, rel)
+        assert err < TOL and rel < REL_BAR, (k, err, rel)
+    print(f"full size: worst tensor-relative gradient distance to the reference {worst_rel:.2e} (bar {REL_BAR:.1e})")
     post = m.state_dict()
     for k in plan.buffer_names(n, ci):
         if "num_batches" in k:
@@ -310,6 +313,65 @@ def test_grad_sync_rccl_single_rank(pkg, dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_native_rccl_entry_single_rank_and_in_a_graph(pkg, dev):
+    """include/wunet_hip.h wunet_comm_*: the library's own RCCL all-reduce (ncclCommInitRank / ncclAllReduce bound at run time).  On
+    the one GPU of the test box: a communicator of world size 1 is created through RCCL, the in-place sum of a buffer is the buffer,
+    GradSync's bucketed backward through it equals the plain backward bit for bit - and, because the collective is enqueued on the
+    caller's streams like a kernel, a whole step (forward, loss, bucketed backward with its all-reduces, fused Adam) captured ONCE in a
+    hipGraph and replayed equals the eager steps (the torch.distributed path had to turn the graph off)."""
+    parallel = importlib.import_module(PKG_NAME + ".parallel")
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    buf = (__import__("ctypes").c_ubyte * 128)()
+    lib = importlib.import_module(PKG_NAME + ".engine").default_engine().lib
+    assert lib.wunet_comm_unique_id(buf) == 0, lib.wunet_last_error()       # RCCL itself is there on a GPU box
+    assert any(buf)
+    comm = parallel.NativeComm(world=1, rank=0, comm_id=bytes(buf))          # ... so this communicator really is an RCCL one
+    t = torch.randn(1 << 20, device=dev)
+    ref = t.clone()
+    comm.all_reduce_(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref)
+    n, ci, B, T = 4, 8, 4, 1024
+    noisy, clean = plan.golden_batch(B, T, 1)
+    x, y = _t(noisy, dev), _t(clean, dev)
+
+    def make(sync):
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+        m = m.to(dev).train()
+        m.grad_sync = sync
+        o = optim_mod.FusedAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999), device_step=True)
+        return m, pkg.smooth_l1_loss(), o
+
+    def step(m, crit, o):
+        o.zero_grad(set_to_none=True)
+        loss = crit(y, m(x))
+        loss.backward()
+        o.step()
+        return loss
+
+    m0, c0, o0 = make(None)
+    m1, c1, o1 = make(parallel.GradSync(n_buckets=3, always_reduce=True, comm=comm))
+    for _ in range(3):
+        step(m0, c0, o0); step(m1, c1, o1)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k                                # the collectives change nothing at world size 1 ...
+    graph = torch.cuda.CUDAGraph()
+    o1.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):                                   # ... and are capturable with the step around them
+        step(m1, c1, o1)
+    o1.advance_host_step(-1)
+    for _ in range(3):
+        step(m0, c0, o0)
+        graph.replay()
+        o1.advance_host_step(1)
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
+    comm.close()
 
 
 def test_chunked_inference_vs_reference_loop(pkg, dev):
@@ -681,33 +743,172 @@ def test_trainer_on_gpu_equals_the_written_out_loop(pkg, dev, tmp_path, graph):
 
 def test_shard_loader_gathers_on_the_gpu(dev, tmp_path):
     """waveform_dataset.ShardLoader with device=cuda - the shard is uploaded once (piecewise from the
-    memory map), every batch is one on-device gather of aligned windows; same draws as the host loader, bit for bit
-    (reference item contract: dataset/waveform_dataset.py:56-67, util/utils.py:101-113)."""
+    memory map), every batch is ONE launch of crop_windows_kernel behind wunet_crop_windows.  Checked against an independent
+    restatement of the reference's item contract (dataset/waveform_dataset.py:56-67 + util/utils.py:101-113), decoded here with
+    the standard library, not with the package: every mixture row is a window [s, s + L) of the item it names with
+    0 <= s <= len - L, the clean row is the SAME window of the clean file, items shorter than L never appear, an item of
+    exactly L samples comes out whole."""
     import wave
     wd = importlib.import_module(PKG_NAME + ".waveform_dataset")
     rng = np.random.default_rng(0)
-    lines = []
-    for i in range(7):
-        T = int(rng.integers(20000, 50000))
+    L = 16384
+    lines, corpus = [], {}
+    for i in range(8):
+        T = L if i == 0 else (9000 if i == 1 else int(rng.integers(20000, 50000)))       # item 0: exactly L; item 1: too short
+        pair = []
         for tag in ("n", "c"):
-            x = (rng.random(T) * 1.8 - 0.9).astype(np.float32)
+            pcm = (rng.random(T) * 1.8 - 0.9)
+            pcm = np.round(pcm * 32767).astype("<i2")
             with wave.open(str(tmp_path / f"{tag}{i}.wav"), "wb") as w:
                 w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000)
-                w.writeframes((x * 32768).astype("<i2").tobytes())
+                w.writeframes(pcm.tobytes())
+            with wave.open(str(tmp_path / f"{tag}{i}.wav"), "rb") as w:                   # what librosa.load(sr=None) returns: int16 / 32768
+                pair.append(np.frombuffer(w.readframes(w.getnframes()), "<i2").astype(np.float32) / 32768.0)
+        corpus[f"n{i}"] = pair
         lines.append(f"{tmp_path / f'n{i}.wav'} {tmp_path / f'c{i}.wav'}")
     (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
     prefix = str(tmp_path / "shard")
-    assert wd.pack_shard(str(tmp_path / "train.txt"), prefix) == 7
+    assert wd.pack_shard(str(tmp_path / "train.txt"), prefix) == 8
     wd.ShardLoader.UPLOAD_CHUNK = 50000                      # several upload pieces even for this small corpus
-    gpu = wd.ShardLoader(prefix, batch_size=8, sample_length=16384, device=dev, seed=5, steps_per_epoch=3)
-    cpu = wd.ShardLoader(prefix, batch_size=8, sample_length=16384, device="cpu", seed=5, steps_per_epoch=3)
-    assert gpu.noisy.is_cuda and gpu.noisy.numel() == cpu.noisy.numel()
-    n = 0
-    for (mg, cg, ng), (mc, cc, nc) in zip(gpu, cpu):
-        assert mg.is_cuda and mg.shape == (8, 1, 16384) and mg.dtype == torch.float32 and mg.is_contiguous()
-        assert ng == nc and torch.equal(mg.cpu(), mc) and torch.equal(cg.cpu(), cc)
+    gpu = wd.ShardLoader(prefix, batch_size=16, sample_length=L, device=dev, seed=5, steps_per_epoch=6)
+    assert gpu.noisy.is_cuda
+    lib = importlib.import_module(PKG_NAME + ".engine").default_engine().lib
+    seen, n = set(), 0
+    for mg, cg, names in gpu:
+        assert mg.is_cuda and mg.shape == (16, 1, L) and mg.dtype == torch.float32 and mg.is_contiguous() and cg.shape == mg.shape
+        mh, ch = mg.cpu().numpy(), cg.cpu().numpy()
+        for b, nm in enumerate(names):
+            noisy_src, clean_src = corpus[nm]
+            assert len(noisy_src) >= L, nm
+            # the window start: match the first 64 samples, then the whole row
+            head = mh[b, 0, :64]
+            cands = [s0 for s0 in range(len(noisy_src) - L + 1) if noisy_src[s0] == head[0] and np.array_equal(noisy_src[s0:s0 + 64], head)]
+            hits = [s0 for s0 in cands if np.array_equal(noisy_src[s0:s0 + L], mh[b, 0])]
+            assert len(hits) >= 1, (nm, b)
+            assert any(np.array_equal(clean_src[s0:s0 + L], ch[b, 0]) for s0 in hits), (nm, b)   # aligned with the mixture
+            seen.add(nm)
         n += 1
-    assert n == 3
+    assert n == 6 and "n1" not in seen and "n0" in seen          # (96 draws over 7 usable items: item 0 is drawn with p > 1 - 1e-6)
+    # same draws as a host loader with the same seed (the host side slices the memory map)
+    cpu = wd.ShardLoader(prefix, batch_size=16, sample_length=L, device="cpu", seed=5, steps_per_epoch=1)
+    g1 = next(iter(wd.ShardLoader(prefix, batch_size=16, sample_length=L, device=dev, seed=5, steps_per_epoch=1)))
+    c1 = next(iter(cpu))
+    assert g1[2] == c1[2] and torch.equal(g1[0].cpu(), c1[0]) and torch.equal(g1[1].cpu(), c1[1])
+    assert lib is not None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the stock trainer's wrap: trainer/base_trainer.py:24-27 puts the model into torch.nn.DataParallel when it sees more than one GPU
+# and reaches it through .module afterwards (:76-79, :102-105)
+@pytest.mark.parametrize("ids", [[0], [0, 0]], ids=["one-replica", "two-replicas-on-one-gpu"])
+def test_model_inside_stock_dataparallel(pkg, dev, ids):
+    """The plugin model wrapped the way the reference's unchanged BaseTrainer wraps it: forward / loss / backward through the
+    wrapper, parameters and state_dict through .module.  [0]: the wrap itself (DataParallel calls .module directly);
+    [0, 0]: the full scatter -> replicate -> parallel_apply (one thread per replica) -> gather path, two replicas sharing the one
+    GPU of the test box: replicas hold non-leaf parameter copies, each thread drives its own context (engine contexts are per
+    (shape, device) and held while in use) - the result must equal the two half-batches run one after the other, summed."""
+    n, ci, B, T = 4, 8, 4, 512
+    sd = plan.golden_state(n, ci, 0)
+    noisy, clean = plan.golden_batch(B, T, 3)
+    x, y = _t(noisy, dev), _t(clean, dev)
+
+    def fresh():
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        return m.to(dev).train()
+
+    # reference result: what nn.DataParallel computes = every shard forwarded by its own replica (own BatchNorm statistics),
+    # the outputs concatenated, ONE loss over the whole batch, gradients summed into the wrapped module
+    shards = len(ids)
+    ref = fresh()
+    outs = [ref(xs) for xs in x.chunk(shards)]
+    out_ref = torch.cat(outs)
+    pkg.mse_loss()(y, out_ref).backward()
+    torch.cuda.synchronize()
+    gref = {k: p.grad.clone() for k, p in ref.named_parameters()}
+
+    m = fresh()
+    try:
+        dp = torch.nn.DataParallel(m, device_ids=ids)          # base_trainer.py:26-27
+        out = dp(x)
+    except (RuntimeError, ValueError, AssertionError) as e:      # torch builds that refuse a repeated device id
+        if len(ids) > 1 and "device" in str(e).lower():
+            pytest.skip(f"this torch refuses device_ids={ids}: {e}")
+        raise
+    assert out.shape == x.shape and out.device == x.device
+    loss = pkg.mse_loss()(y, out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, out_ref, rtol=0, atol=1e-6)
+    for k, p in dp.module.named_parameters():                     # base_trainer.py:76-79 reaches the model through .module
+        assert p.grad is not None, k
+        scale = max(float(gref[k].abs().max()), 1e-6)
+        assert float((p.grad - gref[k]).abs().max()) <= 2e-5 * scale + 1e-7, k
+    state = dp.module.cpu().state_dict()                          # base_trainer.py:102-105: .module.cpu().state_dict(), then back
+    assert set(state) == set(sd) and all(v.device.type == "cpu" for v in state.values())
+    dp.module.to(dev)
+    # replica 0 shares the wrapped module's buffers: its running statistics persist, the other replicas' are dropped (DataParallel
+    # semantics, SURVEY.md section 5)
+    assert int(dp.module.encoder[0].main[1].num_batches_tracked) == int(sd["encoder.0.main.1.num_batches_tracked"]) + 1
+    out2 = dp(x)                                                  # and the wrapper keeps working after the round trip
+    torch.cuda.synchronize()
+    assert torch.isfinite(out2).all()
+
+
+def test_trainer_resumes_into_a_captured_graph(pkg, dev, tmp_path):
+    """Resume (base_trainer.py:62-81) with map_location=device followed by graph replays: the restored Adam step counters must
+    come back as host scalars (a device-side step would synchronise per parameter and abort the capture), an optimiser checkpoint
+    written with Python-int steps (the torch 1.2 of README.md:27) must load, and a changed learning rate must reach the replays."""
+    trainer_mod = importlib.import_module(PKG_NAME + ".trainer")
+    dataset_mod = importlib.import_module(PKG_NAME + ".dataset")
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    n, ci, sl = 3, 8, 1024
+    ds = dataset_mod.Dataset(n_items=24, sample_length=sl, seed=4)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
+
+    def make():
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+        m = m.to(dev)
+        return m, pkg.mse_loss(), optim_mod.FusedAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+
+    cfg = {"root_dir": str(tmp_path), "experiment_name": "r", "trainer": {"epochs": 1, "save_checkpoint_interval": 1, "graph": False}}
+    m1, c1, o1 = make()
+    trainer_mod.Trainer(cfg, False, m1, c1, o1, loader, None).train()                      # epoch 1, eager, writes the checkpoint
+    path = tmp_path / "r" / "checkpoints" / "latest_model.tar"
+    ck = torch.load(path.as_posix())
+    for st in ck["optimizer"]["state"].values():
+        st["step"] = int(st["step"])                                                       # the old on-disk form
+    torch.save(ck, path.as_posix())
+    cfg2 = {"root_dir": str(tmp_path), "experiment_name": "r", "trainer": {"epochs": 2, "save_checkpoint_interval": 0, "graph": True}}
+    m2, c2, o2 = make()
+    tr = trainer_mod.Trainer(cfg2, True, m2, c2, o2, loader, None)
+    assert tr.start_epoch == 2 and tr.use_graph
+    for st in o2.state.values():
+        assert st["step"].device.type == "cpu" and float(st["step"]) == 6.0
+    tr.train()                                                                              # 3 eager warm-up steps, then replays
+    assert tr._graph is not None
+    # the same continuation written out eagerly
+    m3, c3, o3 = make()
+    ck3 = torch.load(path.as_posix(), map_location=dev)
+    o3.load_state_dict(ck3["optimizer"]); m3.load_state_dict(ck3["model"]); m3.train()
+    for mix, cl, _ in loader:
+        o3.zero_grad()
+        c3(cl.to(dev), m3(mix.to(dev))).backward()
+        o3.step()
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m2.state_dict().items(), m3.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert all(int(o2.state[p]["step"]) == 12 for p in m2.parameters())
+    # a new learning rate is an argument of the captured Adam kernels: the driver must capture again, not replay the old value
+    before = [p.detach().clone() for p in m2.parameters()]
+    for g in o2.param_groups:
+        g["lr"] = 0.0
+    mix, cl, _ = next(iter(loader))
+    tr._step(mix.to(dev), cl.to(dev))
+    torch.cuda.synchronize()
+    for a, p in zip(before, m2.parameters()):
+        assert torch.equal(a, p.detach())                                                   # lr = 0: nothing may move
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -187,3 +187,42 @@ def test_trainer_under_torchrun_env_trains_data_parallel(tmp_path):
         opt.step()
     for k, p in m.named_parameters():
         assert torch.equal(p.detach(), p0[k]), k
+
+
+def test_native_comm_entry_at_world_one():
+    """include/wunet_hip.h wunet_comm_*: the library's own all-reduce entry.  The CPU test build has no RCCL: world size 1 must work
+    without it (the sum over one rank is the identity, GradSync's bucketed schedule runs unchanged), a larger world must fail with a
+    message, not crash."""
+    import ctypes
+    import emu_lib
+    from oracle import plan
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    parallel = importlib.import_module(PKG_NAME + ".parallel")
+    eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True)
+    comm = parallel.NativeComm(engine=eng, world=1, rank=0)
+    assert eng.lib.wunet_comm_world(comm.handle) == 1
+    t = torch.arange(10, dtype=torch.float32)
+    assert torch.equal(comm.all_reduce_(t.clone()), t)
+    h = ctypes.c_void_p()
+    assert eng.lib.wunet_comm_create((ctypes.c_ubyte * 128)(), 2, 0, ctypes.byref(h)) != 0
+    assert b"RCCL" in eng.lib.wunet_last_error()
+    n, ci, B, T = 3, 8, 2, 64
+    noisy, clean = plan.golden_batch(B, T, 0)
+
+    def grads(sync):
+        m = importlib.import_module(PKG_NAME + ".model").Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+        m._engine_override = eng
+        m.grad_sync = sync
+        crit = importlib.import_module(PKG_NAME + ".loss").mse_loss()
+        crit._engine_override = eng
+        m.train()
+        crit(torch.from_numpy(clean), m(torch.from_numpy(noisy))).backward()
+        return [p.grad.clone() for p in m.parameters()]
+
+    a = grads(None)
+    b = grads(parallel.GradSync(n_buckets=3, always_reduce=True, comm=comm))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    comm.close()

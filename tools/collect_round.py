@@ -10,50 +10,59 @@ import bench
 tag = sys.argv[1]
 pmc_only = "--pmc-only" in sys.argv[2:]
 F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
-for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_bf16.json"), ("bench_deep16_bf16.json", "bench_deep16_bf16.json"),
+for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_bf16.json"), ("pmc_sq.txt", "pmc_sq.txt"), ("step_timeline.txt", "step_timeline.txt"),
                  ("bench_deep16_split.json", "bench_deep16_split.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
                  ("fwd_kernel_stats.csv", "forward_kernel_stats.csv")):
     if os.path.exists(os.path.join(F, src)):
         shutil.copy(os.path.join(F, src), os.path.join(P, f"{tag}_{dst}"))
-raw = json.load(open(os.path.join(F, "pmc_raw.json")))
 # the PMC runs execute 3 steps (1 warm-up + 2): launches / 3 = launches per step.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE
 # under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section): doubled.
 def lib_name(k):
     """rocprofv3's kernel name -> the name the library's HIP-event profiler (and bench.py's roofline) uses for the same kernel:
-    the split kernels drop their boolean / chunk template arguments (bf16 and the 64-position chunk are spelled out)."""
+    the split kernels drop their boolean template arguments (bf16 is spelled out)."""
     if "<" not in k:
         return k
     base, args = k.split("<", 1)
     a = [t.strip() for t in args.rstrip(">").split(",")]
-    if base in ("conv_h3d_kernel", "conv_h3_kernel"):
+    if base == "conv_h3d_kernel":
         return "%s<%s, %s, %s%s>" % (base, a[0], a[1], a[2], ", bf16" if len(a) > 3 and a[3] == "true" else "")
     if base == "wgrad_h3d_kernel":
-        return "%s<%s, %s%s>" % (base, a[0], a[1], ", bf16" if a[3] == "true" else (", 64" if len(a) > 4 and a[4] == "64" else ""))
+        return "%s<%s, %s%s>" % (base, a[0], a[1], ", bf16" if a[3] == "true" else "")
     if base == "wgrad_h3_kernel":
         return "%s<%s, %s%s>" % (base, a[0], a[1], ", bf16" if len(a) > 4 and a[4] == "true" else "")
     return k
 
 
-acc = {}
-for k, (n, fs) in raw["fetch"].items():
-    wn, ws = raw["write"].get(k, [0, 0.0])
-    e = acc.setdefault(lib_name(k), [0, 0.0, 0, 0.0])
-    e[0] += n; e[1] += fs; e[2] += wn; e[3] += ws
-kern, whole = {}, 0.0
-for k, (n, fs, wn, ws) in acc.items():
-    per = (2.0 * fs / n + (ws / wn if wn else 0.0)) * 1024.0
-    kern[k] = {"launches_per_step": n / 3.0, "FETCH_SIZE_KiB": round(fs / n, 1), "WRITE_SIZE_KiB": round(ws / wn if wn else 0.0, 1),
-               "hbm_bytes_per_launch": int(per)}
-    whole += per * n / 3.0
+def section(name):
+    raw = json.load(open(os.path.join(F, f"pmc_raw_{name}.json")))
+    acc = {}
+    for k, (n, fs) in raw["fetch"].items():
+        wn, ws = raw["write"].get(k, [0, 0.0])
+        e = acc.setdefault(lib_name(k), [0, 0.0, 0, 0.0])
+        e[0] += n; e[1] += fs; e[2] += wn; e[3] += ws
+    kern, whole = {}, 0.0
+    for k, (n, fs, wn, ws) in acc.items():
+        per = (2.0 * fs / n + (ws / wn if wn else 0.0)) * 1024.0
+        kern[k] = {"launches_per_step": n / 3.0, "FETCH_SIZE_KiB": round(fs / n, 1), "WRITE_SIZE_KiB": round(ws / wn if wn else 0.0, 1),
+                   "hbm_bytes_per_launch": int(per)}
+        whole += per * n / 3.0
+    return {"whole_step_bytes": whole, "kernels": kern}
+
+
+head = section("train")
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1; HBM bytes per "
                 "launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction); whole_step_bytes = sum over ALL kernels of one step, "
-                "torch's own (optimizer state init, fills) included",
-       "tag": tag, "source_hash": bench.source_hash(), "whole_step_bytes": whole, "kernels": kern}
+                "torch's own (optimizer state init, fills) included.  Top level: the headline workload (12 levels, batch 64, split GEMMs); "
+                "sections: the same passes of bench.py --gemm fp32 and of --gemm bf16 --layers 16 --frame 65536 --batch 32 (configs[4])",
+       "tag": tag, "source_hash": bench.source_hash(), "whole_step_bytes": head["whole_step_bytes"], "kernels": head["kernels"], "sections": {}}
+for name in ("gemm_fp32", "deep16_bf16"):
+    if os.path.exists(os.path.join(F, f"pmc_raw_{name}.json")):
+        out["sections"][name] = section(name)
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(P, "pmc_traffic.json"), os.path.join(P, f"{tag}_pmc_traffic.json"))
-print("whole step HBM bytes %.3f GB" % (whole / 1e9))
+print("whole step HBM bytes %.3f GB" % (head["whole_step_bytes"] / 1e9), {k: round(v["whole_step_bytes"] / 1e9, 3) for k, v in out["sections"].items()})
 if pmc_only:
     sys.exit(0)
 for name in ("bench.json", "bench_gemm_bf16.json", "bench_deep16_bf16.json", "bench_deep16_split.json", "serial_bench.json", "forward_bench.json"):

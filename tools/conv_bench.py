@@ -53,11 +53,12 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--min-l", type=int, default=256)
     ap.add_argument("--what", choices=["conv", "wgrad"], default="conv", help="conv: forward + data gradient kernels; wgrad: weight gradient kernels")
+    ap.add_argument("--batch", type=int, default=64, help="frames (the 256-MiB Infinity Cache holds a layer's operands at smaller batches)")
     ap.add_argument("cfgs", nargs="*", default=[""])
     a = ap.parse_args()
     lib = importlib.import_module(PKG + "._lib").load_hip()
     dev = torch.device("cuda:0")
-    B = 64
+    B = a.batch
     want = set(a.layers.split(",")) if a.layers else None
     print("%-6s %5s %4s %4s | " % ("layer", "L", "cin", "cout") + " | ".join("%-34s" % c[:34] for c in a.cfgs))
     tot = [[0.0, 0.0] for _ in a.cfgs]

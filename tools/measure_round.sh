@@ -1,16 +1,20 @@
 #!/bin/bash
-# usage (GPU box, through gpurun): tools/measure_round.sh            -> gpurun_out/final/*
-# Every measurement DESIGN.md / profiles/ quote for the round: default bench line, rocprofv3 stats (concurrent and one-stream),
-# PMC passes for HBM traffic (FETCH_SIZE and WRITE_SIZE in separate runs, --kernel-trace only).  tools/collect_round.py <tag> then
-# copies the summaries into profiles/ and rebuilds the same profiles/pmc_traffic.json (stamped with the source hash) here.
+# usage (GPU box, through gpurun): TAG=r3 tools/measure_round.sh            -> gpurun_out/final/*
+# Every measurement DESIGN.md / profiles/ quote for the round: PMC passes for HBM traffic (FETCH_SIZE and WRITE_SIZE in separate runs,
+# --kernel-trace only) of the headline workload and of the two extras that carry their own roofline (exact fp32, configs[4] bf16),
+# the SQ / GRBM counter passes (matrix-pipe utilisation, effective clock), the default bench line, rocprofv3 stats (concurrent and
+# one-stream).  tools/collect_round.py <tag> then copies the summaries into profiles/ and rebuilds profiles/pmc_traffic.json
+# (stamped with the source hash) here.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
-cd $R
-# PMC passes first (collect_round.py --pmc-only stamps profiles/pmc_traffic.json on the box): the bench lines below then carry
-# roofline.traffic measured on THIS box and THIS build
+TAG=${TAG:-r3}
 cd /tmp; export TMPDIR=/tmp
-WUNET_BENCH_NO_MEDIAN=1 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
-WUNET_BENCH_NO_MEDIAN=1 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
-python - <<PY
+pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
+    local name=$1; shift
+    for ctr in FETCH_SIZE WRITE_SIZE; do
+        WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -o p -- \
+            python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras "$@" > /dev/null 2>&1
+    done
+    python - <<PY
 import collections, csv, glob, json
 def agg(pattern, ctr):
     a = collections.defaultdict(lambda: [0, 0.0])
@@ -20,19 +24,36 @@ def agg(pattern, ctr):
             k = r["Kernel_Name"].replace("void ", "").split("(")[0]
             a[k][0] += 1; a[k][1] += float(r["Counter_Value"])
     return {k: v for k, v in a.items()}
-json.dump({"fetch": agg("$O/pmc_fetch/**/*counter_collection.csv", "FETCH_SIZE"), "write": agg("$O/pmc_write/**/*counter_collection.csv", "WRITE_SIZE")},
-          open("$O/pmc_raw.json", "w"))
+json.dump({"fetch": agg("$O/pmc_${name}_FETCH_SIZE/**/*counter_collection.csv", "FETCH_SIZE"),
+           "write": agg("$O/pmc_${name}_WRITE_SIZE/**/*counter_collection.csv", "WRITE_SIZE")}, open("$O/pmc_raw_${name}.json", "w"))
 PY
-rm -rf $O/pmc_fetch $O/pmc_write
-cd $R; python tools/collect_round.py ${TAG:-r2} --pmc-only
-timeout 400 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 400 $O/bench.json; echo
+    rm -rf $O/pmc_${name}_FETCH_SIZE $O/pmc_${name}_WRITE_SIZE
+}
+# PMC passes first (collect_round.py --pmc-only stamps profiles/pmc_traffic.json on the box): the bench line below then carries
+# roofline.traffic measured on THIS box and THIS build
+pmc_pass train
+pmc_pass gemm_fp32 --gemm fp32
+pmc_pass deep16_bf16 --gemm bf16 --layers 16 --frame 65536 --batch 32
+cd $R; python tools/collect_round.py $TAG --pmc-only
+# SQ / GRBM counters of the serial step (one stream: kernels do not overlap, so counters and durations belong to one kernel)
+cd /tmp
+WUNET_NO_SIDE_STREAM=1 WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace \
+    --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
+    --output-format csv -d $O/pmc_sq -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+WUNET_NO_SIDE_STREAM=1 WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace \
+    --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU \
+    --output-format csv -d $O/pmc_grbm -o g -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+python $R/tools/pmc_sq.py $O/pmc_sq $O/pmc_grbm > $O/pmc_sq.txt 2> $O/pmc_sq.err
+rm -rf $O/pmc_sq $O/pmc_grbm
+cd $R
+timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; echo
 timeout 200 python bench.py --gemm bf16 --no-cpu-baseline --no-extras > $O/bench_bf16.json 2>/dev/null
-timeout 300 python bench.py --gemm bf16 --layers 16 --frame 65536 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_deep16_bf16.json 2>/dev/null
 timeout 300 python bench.py --layers 16 --frame 65536 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_deep16_split.json 2>/dev/null
-cd /tmp; export TMPDIR=/tmp
+cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o conc -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python $R/bench.py --no-cpu-baseline --no-extras > $O/serial_bench.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd -o fwd -- python $R/bench.py --mode forward --no-cpu-baseline --no-roofline > $O/forward_bench.json 2>/dev/null
 # keep what collect_round.py needs, drop the bulky traces
 for d in conc serial fwd; do f=$(find $O/$d -name "${d}_kernel_stats.csv" | head -1); cp $f $O/${d}_kernel_stats.csv; g=$(find $O/$d -name "${d}_kernel_trace.csv" | head -1); [ "$d" = serial ] && cp $g $O/serial_kernel_trace.csv; rm -rf $O/$d; done
+python $R/tools/timeline.py $O/serial_kernel_trace.csv > $O/step_timeline.txt 2>/dev/null
 ls -la $O

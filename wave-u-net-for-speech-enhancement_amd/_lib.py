@@ -17,6 +17,7 @@ EXPORTS = [
     "wunet_op_conv1d_dgrad", "wunet_op_conv1d_wgrad", "wunet_profile_enable", "wunet_profile_collect",
     "wunet_adam_step", "wunet_set_h3", "wunet_op_conv1d_split", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split",
     "wunet_backward_range_async", "wunet_backward_join", "wunet_debug_set_conv_trace", "wunet_crop_windows",
+    "wunet_comm_unique_id", "wunet_comm_create", "wunet_comm_allreduce_sum", "wunet_comm_world", "wunet_comm_destroy",
 ]
 
 _vp = ctypes.c_void_p
@@ -55,6 +56,12 @@ def declare(lib):
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
     lib.wunet_profile_collect.restype = ctypes.c_longlong
     lib.wunet_crop_windows.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp]
+    lib.wunet_comm_unique_id.argtypes = [_vp]
+    lib.wunet_comm_create.argtypes = [_vp, _i, _i, ctypes.POINTER(_vp)]
+    lib.wunet_comm_allreduce_sum.argtypes = [_vp, _vp, _sz, _vp]
+    lib.wunet_comm_world.argtypes = [_vp]
+    lib.wunet_comm_destroy.argtypes = [_vp]
+    lib.wunet_comm_destroy.restype = None
     lib.wunet_debug_set_conv_trace.argtypes = [_vp]
     lib.wunet_debug_set_conv_trace.restype = None
     return lib

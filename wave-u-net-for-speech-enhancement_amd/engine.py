@@ -184,6 +184,23 @@ def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, 
 Engine.adam_step = _adam_step
 
 
+def _crop_windows(self, mixture_flat, clean_flat, starts, mixture, clean):
+    """mixture[b, 0, :] = mixture_flat[starts[b] : starts[b] + L], clean likewise (one launch for the batch)."""
+    for t in (mixture_flat, clean_flat, starts, mixture, clean):
+        self._require(t, "crop tensor")
+    if starts.dtype != torch.int64 or mixture_flat.dtype != torch.float32 or mixture.dtype != torch.float32:
+        raise WunetError("crop_windows: float32 arrays and int64 starts expected")
+    if mixture_flat.numel() != clean_flat.numel() or mixture.shape != clean.shape or starts.numel() != mixture.shape[0]:
+        raise WunetError("crop_windows: shape mismatch")
+    B, L = mixture.shape[0], mixture.shape[-1]
+    with self._device_guard(mixture.device):
+        self._check(self.lib.wunet_crop_windows(mixture_flat.data_ptr(), clean_flat.data_ptr(), starts.data_ptr(), mixture_flat.numel(),
+                                                B, L, mixture.data_ptr(), clean.data_ptr(), self._stream(mixture.device)))
+
+
+Engine.crop_windows = _crop_windows
+
+
 class _CtxHold:
     """`with engine._using(shape...) as handle`: the context cannot be evicted while the block runs."""
 

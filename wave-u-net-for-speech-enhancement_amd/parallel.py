@@ -8,8 +8,52 @@ running statistics are not reduced, and with equal shards the summed gradient of
 loss equals the average of the per-shard mean-loss gradients - so buckets are summed and scaled by
 1/world_size.  Every rank then takes the identical optimiser step; no parameter broadcast follows.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+
+class NativeComm:
+    """The RCCL communicator behind the C ABI (include/wunet_hip.h: wunet_comm_*): one per process and GPU.  torch.distributed is
+    used ONLY to carry rank 0's 128-byte RCCL id to the other ranks (any initialised backend does; pass `comm_id` to do without).
+    `all_reduce_` enqueues the in-place sum on torch's CURRENT stream like a kernel - it can be captured into the step's hipGraph,
+    which torch's own process-group collectives (their watchdog, their private stream) make awkward."""
+
+    def __init__(self, engine=None, group=None, comm_id=None, world=None, rank=None):
+        from .engine import default_engine
+        self.engine = engine if engine is not None else default_engine()
+        lib = self.engine.lib
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world, self.rank = world, rank
+        buf = (ctypes.c_ubyte * 128)()
+        if comm_id is None:
+            box = [None]
+            if rank == 0:
+                rc = lib.wunet_comm_unique_id(buf)
+                if rc != 0 and world > 1:           # (world size 1 runs without RCCL: the CPU test build)
+                    self.engine._check(rc)
+                box[0] = bytes(buf)
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            comm_id = box[0]
+        buf = (ctypes.c_ubyte * 128)(*comm_id)
+        self.handle = ctypes.c_void_p()
+        self.engine._check(lib.wunet_comm_create(buf, world, rank, ctypes.byref(self.handle)))
+
+    def all_reduce_(self, tensor):
+        if tensor.dtype != torch.float32 or not tensor.is_contiguous():
+            raise TypeError("NativeComm.all_reduce_: contiguous float32 expected")
+        stream = None if self.engine.host_memory else ctypes.c_void_p(torch.cuda.current_stream(tensor.device).cuda_stream)
+        self.engine._check(self.engine.lib.wunet_comm_allreduce_sum(self.handle, tensor.data_ptr(), tensor.numel(), stream))
+        return tensor
+
+    def close(self):
+        if self.handle:
+            self.engine.lib.wunet_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 def bucket_ranges(param_numels, n_conv_layers, n_buckets):
@@ -48,8 +92,9 @@ class GradSync:
     scale_in_optimizer=True: the 1/world_size of the average is left to the optimiser step (optim.FusedAdam.grad_scale - the
     same rounding, four launches and 2 x 40 MB of traffic less); the default scales the buckets here so any optimiser works."""
 
-    def __init__(self, process_group=None, n_buckets=4, always_reduce=False, scale_in_optimizer=False):
+    def __init__(self, process_group=None, n_buckets=4, always_reduce=False, scale_in_optimizer=False, comm=None):
         self.group = process_group
+        self.comm = comm                        # a NativeComm: the collectives go through the library's own RCCL entry (capturable)
         self.n_buckets = n_buckets
         self.always_reduce = always_reduce      # issue the collectives even at world_size 1 (single-GPU RCCL smoke test)
         self.scale_in_optimizer = scale_in_optimizer
@@ -57,6 +102,8 @@ class GradSync:
         self._launch_streams = {}
 
     def world_size(self):
+        if self.comm is not None:
+            return self.comm.world
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
 
     def ranges_for(self, params, n_conv_layers):
@@ -73,9 +120,11 @@ class GradSync:
     def run(self, engine, owner, noisy, params, out, grad_out, ws, grads, flat):
         nl = 2 * owner.n_layers + 1
         world = self.world_size()
-        reduce = world > 1 or (self.always_reduce and dist.is_initialized())
+        reduce = world > 1 or (self.always_reduce and (dist.is_initialized() or self.comm is not None))
         on_gpu = noisy.is_cuda
         pending = []
+        if self.comm is not None and reduce:
+            return self._run_native(engine, owner, noisy, params, out, grad_out, ws, grads, flat, world)
         for lb, le, fb, fe in self.ranges_for(params, nl):
             engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out, ws, grads,
                             layer_range=(lb, le), join=not (reduce and on_gpu))
@@ -96,3 +145,29 @@ class GradSync:
             work.wait()                  # stream-level dependency on the RCCL stream, host does not block
             if not self.scale_in_optimizer:
                 seg.mul_(1.0 / world)
+
+    def _run_native(self, engine, owner, noisy, params, out, grad_out, ws, grads, flat, world):
+        """The same schedule with the library's own RCCL entry: every bucket's all-reduce is enqueued on the launch stream C behind
+        the events of S (data path) and W (weight gradients); S joins C once at the end.  Nothing here touches a process group
+        or a host-side work handle, so the whole backward - collectives included - is capturable in the step's hipGraph."""
+        nl = 2 * owner.n_layers + 1
+        on_gpu = noisy.is_cuda
+        main = torch.cuda.current_stream(noisy.device) if on_gpu else None
+        launch = self._launch_stream(noisy.device) if on_gpu else None
+        for lb, le, fb, fe in self.ranges_for(params, nl):
+            engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out, ws, grads,
+                            layer_range=(lb, le), join=not on_gpu)
+            seg = flat[fb:fe]
+            if on_gpu:
+                launch.wait_stream(main)
+                with torch.cuda.stream(launch):
+                    engine.join_weight_gradients(owner.n_layers, owner.channels_interval, noisy)
+                    self.comm.all_reduce_(seg)
+                    if not self.scale_in_optimizer:
+                        seg.mul_(1.0 / world)
+            else:
+                self.comm.all_reduce_(seg)
+                if not self.scale_in_optimizer:
+                    seg.mul_(1.0 / world)
+        if on_gpu:
+            main.wait_stream(launch)

@@ -50,18 +50,23 @@ class Trainer:
         self.loss_function = loss_function
         self.optimizer = optimizer
         fused = isinstance(optimizer, FusedAdam)
+        tcfg = config["trainer"]
+        # "native_rccl": the bucket all-reduces through the library's own RCCL entry (wunet_comm_*, capturable in the step graph)
+        # instead of torch.distributed's process group; default: torch.distributed (measured on hardware only at world size 1 so far)
+        native = bool(tcfg.get("native_rccl", os.environ.get("WUNET_NATIVE_RCCL", "0") not in ("", "0"))) and self.device.type == "cuda"
         if self.world > 1:
-            self.model.grad_sync = GradSync(scale_in_optimizer=fused)
+            from .parallel import NativeComm
+            self.model.grad_sync = GradSync(scale_in_optimizer=fused, comm=NativeComm() if native else None)
             if fused:
                 optimizer.grad_scale = 1.0 / self.world
         self.train_data_loader = self._shard_loader(train_dataloader)
         self.validation_data_loader = validation_dataloader      # accepted for signature compatibility, unused
-        tcfg = config["trainer"]
         self.epochs = tcfg["epochs"]
         self.save_checkpoint_interval = tcfg.get("save_checkpoint_interval", 0)
         self.use_graph = bool(tcfg.get("graph", os.environ.get("WUNET_GRAPH", "0") not in ("", "0")))
-        if self.use_graph and not (fused and self.device.type == "cuda" and self.world == 1):
-            # (RCCL collectives inside a captured graph are left for a later round: the eager path overlaps them already)
+        if self.use_graph and not (fused and self.device.type == "cuda" and (self.world == 1 or native)):
+            # (torch.distributed's collectives stay outside a captured graph: their eager path overlaps them with the backward already;
+            #  the native RCCL entry enqueues on the captured streams and is replayed with the step)
             self.use_graph = False
         if self.use_graph:
             optimizer.device_step = True

@@ -146,7 +146,7 @@ class ShardLoader:
     Items shorter than `sample_length` are never drawn (the reference asserts on them).  Every rank of a data-parallel
     job passes its own `seed` (e.g. seed + rank) and draws independently, like shuffled per-rank loaders."""
 
-    def __init__(self, prefix, batch_size, sample_length=16384, device="cpu", seed=0, steps_per_epoch=None):
+    def __init__(self, prefix, batch_size, sample_length=16384, device="cpu", seed=0, steps_per_epoch=None, engine=None):
         idx = json.load(open(prefix + ".index.json"))
         self.names = idx["names"]
         starts = np.asarray(idx["starts"], np.int64)
@@ -164,7 +164,7 @@ class ShardLoader:
         self.batch_size, self.sample_length = batch_size, sample_length
         self.steps = steps_per_epoch if steps_per_epoch is not None else max(1, len(usable) // batch_size)
         self.gen = torch.Generator().manual_seed(seed)
-        self.ramp = torch.arange(sample_length, device=self.device)
+        self.engine = engine                     # tests inject the emulator engine; a GPU loader takes the default (HIP) engine
 
     UPLOAD_CHUNK = 1 << 26          # floats per staged piece (256 MB): the corpus is never copied into host RAM as a whole
 
@@ -190,10 +190,25 @@ class ShardLoader:
         inner = torch.minimum(inner, self.spare[pick] - 1)
         return pick, self.starts[pick] + inner
 
+    def crop(self, first):
+        """The batch of aligned windows that start at `first` (host int64 [B], offsets into the flat arrays): mixture and clean
+        [B, 1, L].  On a GPU this is ONE launch of the HIP crop kernel behind the C ABI (wunet_crop_windows, csrc/wunet_ops.cpp);
+        a host loader (device="cpu": the reference's DataLoader worker side) slices the memory map."""
+        B, L = first.numel(), self.sample_length
+        if self.device.type != "cuda" and self.engine is None:
+            index = first[:, None] + torch.arange(L)[None, :]
+            return self.noisy[index].unsqueeze(1), self.clean[index].unsqueeze(1)
+        if self.engine is None:
+            from .engine import default_engine
+            self.engine = default_engine()
+        mixture = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
+        clean = torch.empty(B, 1, L, dtype=torch.float32, device=self.device)
+        starts = first.to(self.device, non_blocking=True)
+        self.engine.crop_windows(self.noisy, self.clean, starts, mixture, clean)
+        return mixture, clean
+
     def __iter__(self):
         for _ in range(self.steps):
             pick, first = self.draw()
-            index = first.to(self.device, non_blocking=True)[:, None] + self.ramp[None, :]     # [B, L] gather indices
-            mixture = self.noisy[index].unsqueeze(1)
-            clean = self.clean[index].unsqueeze(1)
+            mixture, clean = self.crop(first)
             yield mixture, clean, [self.names[i] for i in pick.tolist()]
