@@ -156,8 +156,9 @@ def roofline_of(rows, nprof, pmc, step_algorithmic_bytes):
             "avg_launch_ms": avg_ms, "launches_per_step": top["launches"] / nprof,
             "mfma_kernels_ms_per_step": mfma_ms,
             "all_mfma_kernels_achieved": sum(r["flops"] for r in gemm_rows) / nprof / (mfma_ms * 1e-3) / 1e12,
-            "top5": [{"kernel": r["kernel"], "ms_per_step": r["ms"] / nprof,
-                      "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12} for r in gemm_rows[:(999 if os.environ.get("WUNET_BENCH_ALL") else 5)]],
+            "top5": [{"kernel": r["kernel"], "ms_per_step": r["ms"] / nprof, "launches_per_step": r["launches"] / nprof,
+                      "tflops": r["flops"] / (r["ms"] * 1e-3) / 1e12, "algorithmic_bytes_per_step": r["bytes"] / nprof}
+                     for r in gemm_rows[:(999 if os.environ.get("WUNET_BENCH_ALL") else 5)]],
             "memory_bound_kernels": memory_bound,
             "memory_bound_ms_per_step": sum(m["ms_per_step"] for m in memory_bound),
             "kernels_timed_per_step": sum(r["launches"] for r in rows) / nprof}
@@ -264,6 +265,11 @@ def main():
                          "fused Adam with its device-side step counter; SURVEY.md section 8 f2).  auto = off: measured on MI355X / "
                          "ROCm 7.0 the replay of the ~270-node graph costs the host as much as the eager launches (4.9 ms) and the "
                          "GPU 4 %% more (6.65 vs 6.41 ms per step), so the headline stays eager")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="the gradient all-reduce through the library's own RCCL entry (include/wunet_hip.h wunet_comm_*: enqueued on the "
+                         "backward's streams, capturable with --graph on) instead of torch.distributed's process group; at --gpus 1 the "
+                         "bucketed collectives are issued anyway (world size 1), so their cost inside the step can be measured on one GPU")
+    ap.add_argument("--seed", type=int, default=0, help="extra measurements only: seed of the initial weights and of the synthetic batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and eval-forward side measurements")
@@ -290,19 +296,20 @@ def main():
     parallel = importlib.import_module(PKG + ".parallel")
     engine_mod = importlib.import_module(PKG + ".engine")
 
-    torch.manual_seed(0)                         # same init on every rank (reference train.py:12)
+    torch.manual_seed(args.seed)                 # same init on every rank (reference train.py:12)
     model = pkg.Model(n_layers=args.layers, channels_interval=CI).to(device).train()
     crit = pkg.smooth_l1_loss()
     optim_mod = importlib.import_module(PKG + ".optim")
     adam_cls = torch.optim.Adam if args.torch_adam else optim_mod.FusedAdam     # reference train.py:31-35
     opt = adam_cls(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
-    if world > 1:
+    if world > 1 or args.native_rccl:
         # bucketed RCCL all-reduce inside the backward; the 1/world of the average is folded into the fused Adam step
         # (same rounding, four launches and 2 x 40 MB of traffic less per step) unless torch's optimiser is used
-        model.grad_sync = parallel.GradSync(n_buckets=4, scale_in_optimizer=not args.torch_adam)
+        comm = parallel.NativeComm() if args.native_rccl else None
+        model.grad_sync = parallel.GradSync(n_buckets=4, scale_in_optimizer=not args.torch_adam, comm=comm, always_reduce=args.native_rccl)
         if not args.torch_adam:
             opt.grad_scale = 1.0 / world
-    noisy, clean = synthetic_batch(args.batch, device, seed=rank, frame=args.frame)
+    noisy, clean = synthetic_batch(args.batch, device, seed=rank + 1000 * args.seed, frame=args.frame)
     default_net = args.layers == N_LAYERS and args.frame == FRAME
     fwd_flop, fwd_bytes = net_flops_bytes(args.layers, CI, args.frame)
     step_flop = 3.0 * fwd_flop - 2.0 * (1 * CI * 15 * args.frame) if args.mode == "train" else fwd_flop   # no dgrad for encoder[0]
@@ -322,7 +329,7 @@ def main():
         opt.step()
         return loss
 
-    use_graph = args.mode == "train" and args.graph == "on"
+    use_graph = args.mode == "train" and args.graph == "on" and (world == 1 or args.native_rccl)
     eager_step = step
     if use_graph:
         opt.device_step = True                   # the step counter and bias corrections live on the device: replayable
@@ -481,7 +488,8 @@ def main():
                                    "training-mode forward + smooth_l1 + backward + " + ("torch.optim.Adam" if args.torch_adam else "fused HIP Adam") + " step "
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",
                        "global_batch": args.batch * world, "frame": args.frame,
-                       "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")},
+                       "parallelism": f"dp{world}" + (" (RCCL bucketed all-reduce, per-GPU BatchNorm)" if world > 1 else "")
+                                      + (" [collectives through the library's RCCL entry]" if args.native_rccl else "")},
             "whole_step_tflops_per_gpu": per_gpu_fps * step_flop / 1e12,
             # against the roof of the arithmetic that ran: 2500 / 3 TF for the fp16-split GEMMs, 2500 TF bf16, 157.3 TF exact fp32
             "whole_step_frac_of_gemm_peak": per_gpu_fps * step_flop / 1e12 / (PEAK_F16_MFMA_TFLOPS if bf16_gemm else PEAK_SPLIT_TFLOPS if split_gemm
@@ -490,7 +498,7 @@ def main():
             "whole_step_algorithmic_hbm_frac": per_gpu_fps * step_bytes / 1e9 / PEAK_HBM_GBS,
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
-            "step_launch": "one hipGraph replay per step" if use_graph else "eager (~270 kernel launches per step)",
+            "step_launch": "one hipGraph replay per step" if use_graph else "eager launches",
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         print(json.dumps(result))

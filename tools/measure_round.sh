@@ -47,7 +47,17 @@ python $R/tools/pmc_sq.py $O/pmc_sq $O/pmc_grbm > $O/pmc_sq.txt 2> $O/pmc_sq.err
 rm -rf $O/pmc_sq $O/pmc_grbm
 cd $R
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; echo
+WUNET_BENCH_ALL=1 timeout 200 python bench.py --no-cpu-baseline --no-extras > $O/bench_all_kernels.json 2>/dev/null
+python tools/traffic_table.py $O/bench_all_kernels.json > $O/traffic_by_family.txt 2>&1
 timeout 200 python bench.py --gemm bf16 --no-cpu-baseline --no-extras > $O/bench_bf16.json 2>/dev/null
+# the collectives' cost inside the step on one GPU (world size 1 through the library's RCCL entry), eager and as one captured graph
+timeout 200 python bench.py --native-rccl --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_eager.json 2>/dev/null
+timeout 200 python bench.py --native-rccl --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_graph.json 2>/dev/null
+timeout 200 python bench.py --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_graph.json 2>/dev/null
+# training soak on two more seeds: final loss after S steps, default split GEMMs against exact fp32
+for seed in 1 2; do for S in 100 300; do for gm in split fp32; do
+  timeout 200 python bench.py --seed $seed --steps $S --warmup 0 --gemm $gm --no-cpu-baseline --no-extras --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('seed $seed steps $S gemm $gm final_loss', d['final_loss'], 'ms', round(d['ms_per_step'],3))"
+done; done; done > $O/training_soak.txt 2>&1
 timeout 300 python bench.py --layers 16 --frame 65536 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_deep16_split.json 2>/dev/null
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o conc -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
