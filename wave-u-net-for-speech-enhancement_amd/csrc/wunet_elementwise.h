@@ -361,7 +361,6 @@ struct PassAArgs {
     int coff;            // ENC: channel offset of the skip part inside dXdec
     int B, C, L, logL;
     float up_scale;      // UP: (float)(Lt-1)/(2Lt-1)
-    int no_fast;         // UP: A/B switch, generic upsample^T walk for every thread
     int Lt;              // samples of a row that exist (<= L, the power-of-two row stride; PrepArgs::Lt): the padding gets no gradient
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
@@ -439,7 +438,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             // interior threads: ATen's source pair of output j is ((j-1)>>1, +1) (checked against the exact coordinates), so
             // input i receives, in ascending j, l1(2i-1) d[2i-1] + l1(2i) d[2i] + l0(2i+1) d[2i+1] + l0(2i+2) d[2i+2]: four
             // multiply-adds instead of eleven rounds of compare-and-select (the pass is VALU-heavy: ~300 -> ~130 instructions)
-            bool fast = !A.no_fast && l >= 4 && l + 8 <= A.Lt;
+            bool fast = l >= 4 && l + 8 <= A.Lt;
             float c0[10], c1[10];
             if (fast) {
 #pragma unroll
