@@ -274,6 +274,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the exact-fp32 and eval-forward side measurements")
     args = ap.parse_args()
+    # the contract: rank 0 prints ONE JSON line.  Libraries write to the C-level stdout behind Python's back (RCCL prints a version
+    # banner when a communicator is created): everything but the result line goes to stderr
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     if args.gemm is not None:
         os.environ["WUNET_H3"] = {"split": "1", "fp32": "0", "bf16": "3"}[args.gemm]
@@ -501,7 +506,8 @@ def main():
             "step_launch": "one hipGraph replay per step" if use_graph else "eager launches",
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
-        print(json.dumps(result))
+        result_out.write(json.dumps(result) + "\n")
+        result_out.flush()
 
 
 if __name__ == "__main__":

@@ -90,7 +90,9 @@ class GradSync:
     all-reduce is enqueued from C; RCCL's own stream then waits for C.  S waits for the collectives once, after the last range.
 
     scale_in_optimizer=True: the 1/world_size of the average is left to the optimiser step (optim.FusedAdam.grad_scale - the
-    same rounding, four launches and 2 x 40 MB of traffic less); the default scales the buckets here so any optimiser works."""
+    same rounding, four launches and 2 x 40 MB of traffic less); the default scales the buckets here so any optimiser works.
+    With it, `param.grad` and `model.last_flat_grad` hold the SUM over the ranks until the step: anything else that reads them
+    (gradient clipping, logging a norm) must apply the 1/world itself - or use the default."""
 
     def __init__(self, process_group=None, n_buckets=4, always_reduce=False, scale_in_optimizer=False, comm=None):
         self.group = process_group
