@@ -134,6 +134,21 @@ __device__ __forceinline__ void bn_eval_core(const BnFwdArgs& A, int c)
     A.s[c] = A.beta[c] - A.running_mean[c] * a;
 }
 
+// Eval mode: the BatchNorm scale / shift of EVERY layer in one launch - they only depend on the running statistics, so nothing
+// of it belongs on the layer-to-layer chain (25 launches of ~4 us less per eval forward).  grid = (ceil(maxC / 256), layers).
+struct BnEvalDesc { const float* gamma; const float* beta; const float* running_mean; const float* running_var; float* a; float* s; int C; };
+struct BnEvalTable { BnEvalDesc d[WUNET_MAX_CONV_LAYERS]; };
+static __global__ __launch_bounds__(WUNET_THREADS) void bn_eval_all_kernel(BnEvalTable T)
+{
+    const BnEvalDesc& d = T.d[blockIdx.y];
+    const int c = blockIdx.x * WUNET_THREADS + threadIdx.x;
+    if (c >= d.C) return;
+    BnFwdArgs A{};
+    A.gamma = d.gamma; A.beta = d.beta; A.running_mean = const_cast<float*>(d.running_mean); A.running_var = const_cast<float*>(d.running_var);
+    A.a = d.a; A.s = d.s;
+    bn_eval_core(A, c);
+}
+
 static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(BnFwdArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];

@@ -123,6 +123,20 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             bside = side;
         }
     }
+    if (!training) {
+        // eval mode: every layer's BatchNorm scale / shift from the running statistics, one launch ahead of the chain
+        BnEvalTable T{};
+        int maxc = 1;
+        for (int i = 0; i < c->NL; ++i) {
+            const LayerPlan& l = c->ly[i];
+            BnEvalDesc& d = T.d[i];
+            d.gamma = params[4 * i + 2]; d.beta = params[4 * i + 3]; d.running_mean = running[2 * i]; d.running_var = running[2 * i + 1];
+            d.a = ws + l.a; d.s = ws + l.s; d.C = l.cout;
+            if (l.cout > maxc) maxc = l.cout;
+        }
+        WUNET_LAUNCH(bn_eval_all_kernel, dim3((unsigned)((maxc + WUNET_THREADS - 1) / WUNET_THREADS), (unsigned)c->NL), dim3(WUNET_THREADS), 0, st, T);
+        WUNET_CHECK_LAUNCH();
+    }
     for (int i = 0; i < c->NL; ++i) {
         const LayerPlan& l = c->ly[i];
         // (packs on the side stream: the operand scales and the split pack are first read by layer 1, the fp32 pack by the first
@@ -228,10 +242,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         const bool ev_need = !training && c->h3 && l.feeds_h3;
         const bool ev_epi = ev_need && (l.first || (l.h3f && !split));
         float* const xrows = ws + c->stats_off;         // (eval: the statistics rows are free)
-        if (ev_epi) {
-            WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
-            WUNET_CHECK_LAUNCH();
-        }
+        // (eval: a / s of every layer are already there, bn_eval_all_kernel)
         if (l.first) {
             prof_begin(st, "conv_first_kernel<15>", 2.0 * c->B * l.L * l.cout * 15.0, 4.0 * c->B * l.L * (1.0 + l.cout));
             WUNET_LAUNCH(conv_first_kernel<15>, dim3((unsigned)l.f.grid_x), dim3(WUNET_THREADS), 0, st, xin, params[4 * i], params[4 * i + 1],
@@ -279,11 +290,11 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             b.rows = rs;
             WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout, rs), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
                          tiny ? 1 : l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off, l.Lt);
-            if (rs > 1) {
+            if (rs > 1 && training) {
                 WUNET_CHECK_LAUNCH();
                 WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
             }
-        } else {
+        } else if (training) {
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
         WUNET_CHECK_LAUNCH();
