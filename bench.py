@@ -411,6 +411,14 @@ def main():
     extras = None
     if rank == 0 and world == 1 and args.mode == "train" and default_net and not args.no_extras:
         extras = {}
+        # (first, while the allocator still holds the headline run's blocks: every forward takes its workspace from torch)
+        model.eval()
+
+        def fwd():
+            with torch.no_grad():
+                model(noisy)
+        extras["eval_forward"] = timed(fwd, 10, 20, args.batch, "eval-mode forward only (BASELINE configs[1], enhancement.py path), default GEMM arithmetic")
+        model.train()
         torch.manual_seed(0)
         m32 = pkg.Model(n_layers=args.layers, channels_interval=CI).to(device).train()
         m32._engine_override = engine_mod.Engine(h3=0)
@@ -429,7 +437,6 @@ def main():
             extras["gemm_fp32"]["roofline"] = roofline_of(kernel_rows(m32._engine_override.lib, step32, 3), 3, load_pmc_traffic("gemm_fp32"),
                                                           args.batch * step_bytes)
         del m32, o32, c32
-        torch.cuda.empty_cache()
         # BASELINE.json configs[4]: "24-level / 65536-sample deep variant, bf16, batch=32" - 16 levels is the deepest net that exists
         # at 65536 samples: bf16 operands, one bf16 MFMA pass, f32 accumulation / BatchNorm / gradients
         try:
@@ -457,16 +464,8 @@ def main():
                 d16["roofline"] = roofline_of(kernel_rows(e16.lib, step16, 3), 3, load_pmc_traffic("deep16_bf16"), 32 * 3.0 * f16by)
             extras["deep16_bf16"] = d16
             del m16, o16, c16, n16, cl16
-            torch.cuda.empty_cache()
         except Exception as e:      # (an extra must never take the headline line down with it)
             extras["deep16_bf16"] = {"error": f"{type(e).__name__}: {e}"}
-        model.eval()
-
-        def fwd():
-            with torch.no_grad():
-                model(noisy)
-        extras["eval_forward"] = timed(fwd, 5, 20, args.batch, "eval-mode forward only (BASELINE configs[1], enhancement.py path), default GEMM arithmetic")
-        model.train()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
