@@ -86,12 +86,15 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
             p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.Lt;
         }
+        // the last layer on the split kernels: its g is recomputed from the head gradient by gz_split_h3_kernel (HEAD mode), not stored
+        const bool head_in_gz = i == NL - 1 && i > 0 && l.h3d && !fuse && !tiny;
         {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
             const double pe = (double)c->B * l.cout * l.L;
             const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : "pass_a_kernel<ENC>";
-            prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? 8.0 : i >= n ? 16.0 : 14.0) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
+            prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : i >= n ? 16.0 : 14.0) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
         }
         if (i == NL - 1) {
+            if (head_in_gz) p.gpre = nullptr;
             p.g0 = ws + c->gh_off; p.g1 = params[4 * NL]; p.hpart = ws + c->hpart2_off;
             WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);      // (the last layer has T >= 4 samples)
             prof_end(st);
@@ -143,17 +146,19 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     const size_t nt = (size_t)c->B * c8 * (l.L / 4);
                     size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                     if (hb > 8192) hb = 8192;
-                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * (8.0 + (c->bf ? 2.0 : 4.0)));
+                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * ((head_in_gz ? 4.0 : 8.0) + (c->bf ? 2.0 : 4.0)));
+                    GzHeadArgs hd{};
+                    if (head_in_gz) { hd.gh = ws + c->gh_off; hd.wh = params[4 * NL]; hd.a = ws + l.a; hd.s = ws + l.s; }
                     if (fin_in_gz)
                         WUNET_LAUNCH(gz_split_h3_kernel<true>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                      (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
                                      ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b);
+                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b, hd);
                     else
                         WUNET_LAUNCH(gz_split_h3_kernel<false>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                      (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
                                      ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b);
+                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b, hd);
                     prof_end(st);
                 } else if (tiny)
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             mz = fmaxf(mz, fabsf(zc));
         }
         if (FUSE) { keep_g = go; keep_z = z; keep_i = zi; keep_l = l; have = true; }      // the thread's only iteration
-        else wunet_st4(A.gpre + zi, go);
+        else if (A.gpre) wunet_st4(A.gpre + zi, go);          // (nullptr: the consumer recomputes g - gz_split_h3_kernel's HEAD mode)
     }
     block_sum2(s1, s2, red);
     if (FUSE) {

@@ -241,13 +241,17 @@ static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(W
 // few hundred loads that hit the L2 - instead of in a launch of its own in front of this one: on those levels that launch is 4 us of
 // latency + a kernel boundary on the backward's critical path.  Block 0 publishes the results.  The sums run over the rows in order,
 // in double: the same numbers as the tree of the separate kernel to the last bit of the float results.
+// HEAD (the last decoder layer, whose only consumer is the 1x1 head): its g = wh[c] * gh * LeakyReLU'(a z + s) is a function of the
+// one-channel head gradient gh [B][L] (pass_a_kernel<A_HEAD>'s arithmetic, bit for bit) - recomputed here from gh (1 / C of the
+// bytes) instead of written by pass A and read back: the largest layer's g (100 MB at batch 64) never exists.
+struct GzHeadArgs { const float* gh; const float* wh; const float* a; const float* s; };
 #define WUNET_GZ_FIN_LOADS 1536   // (sweep 1152 / 2048 / 3100 / all: 5.41 / 5.42 / 5.46 / 5.50 ms per step - beyond the 512-sample level the prologue costs more than the launch)
 #define WUNET_GZ_FIN_C 512
 template <bool FIN>
 __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                      const float* k3, const float* bound, float* sc, wunet_half* hi,
                                                                      wunet_half* lo, int B, int C, int C8, int L, int logL, int bf, int Lt,
-                                                                     BnBwdArgs F)
+                                                                     BnBwdArgs F, GzHeadArgs H)
 {
     __shared__ float red[WUNET_THREADS];
     __shared__ float ks[FIN ? 3 * WUNET_GZ_FIN_C : 3];
@@ -320,13 +324,25 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
             const size_t row = i >> (logL - 2);
             const int b = (int)(row / (size_t)C8), c8 = (int)(row - (size_t)b * C8);
             wunet_f4 v[8];
+            wunet_f4 gh4 = wunet_f4{0.f, 0.f, 0.f, 0.f};
+            if (H.gh) gh4 = wunet_ld4(H.gh + (size_t)b * L + 4 * l4);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = c8 * 8 + e;
                 const bool ok = c < C;
                 const size_t o = ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4;
-                const wunet_f4 gv = wunet_ld4(g + o), zv = wunet_ld4(z + o);
                 const int cc = ok ? c : 0;
+                const wunet_f4 zv = wunet_ld4(z + o);
+                wunet_f4 gv;
+                if (H.gh) {
+                    const float wh = H.wh[cc], ha = H.a[cc], hs = H.s[cc];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float t = wh * gh4[j];
+                        if (!(ha * zv[j] + hs > 0.0f)) t *= WUNET_SLOPE;
+                        gv[j] = t;
+                    }
+                } else gv = wunet_ld4(g + o);
                 const float a = FIN ? ks[cc] : k1[cc], bb = FIN ? ks[WUNET_GZ_FIN_C + cc] : k2[cc], d = FIN ? ks[2 * WUNET_GZ_FIN_C + cc] : k3[cc];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[e][j] = (ok && 4 * l4 + j < Lt) ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;     // (row padding: no gradient)
