@@ -198,6 +198,13 @@ __device__ __forceinline__ void wunet_pow2_scale(float bound, float& s, float& i
     }
 }
 
+// max |v| folded into *slot (non-negative floats order like their bit patterns; NaN / inf saturate to the largest finite float so a
+// scale derived from it stays defined).  Order independent: the result does not depend on which block arrives when.
+__device__ __forceinline__ void wunet_atomic_absmax(float* slot, float v)
+{
+    const unsigned u = wunet_fbits(v) & 0x7fffffffu;
+    atomicMax(reinterpret_cast<unsigned*>(slot), u < 0x7f800000u ? u : 0x7f7fffffu);
+}
 #define WUNET_THREADS 256
 #define WUNET_WAVES 4
 #define WUNET_SLOPE 0.1f

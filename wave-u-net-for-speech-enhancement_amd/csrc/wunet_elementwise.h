@@ -651,7 +651,8 @@ static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_reduce_kernel(cons
 // x all Cout channels (the K+3 inputs sit in registers, the weights are wave-uniform scalar loads), one 16-byte
 // store per channel; BN statistics of the bias-free conv per (wave, channel) like the MFMA kernels
 // (stats [Cout][gridDim.x*4][2], one row per wave = 256 samples).  L >= 256: a wave lies inside one batch item.
-// Eval mode: ev_a / ev_s (this layer's BatchNorm scale / shift, known before the conv) and xrows [gridDim.x]: the block's
+// Eval mode: ev_a / ev_s (this layer's BatchNorm scale / shift, known before the conv) and xrows (ONE float, the layer's xb slot, cleared by
+// h3_scales_kernel: every block folds its maximum into it with one atomic max - order independent, so deterministic): the block's
 // max |a z + s|, the activation bound the consumer's split-operand scale derives from.
 template <int K>
 __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* x, const float* w, const float* bias, float* out,
@@ -718,25 +719,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void conv_first_kernel(const float* 
         for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
         if (lane == 0) xm[wave] = amax;
         __syncthreads();
-        if (threadIdx.x == 0) xrows[blockIdx.x] = fmaxf(fmaxf(xm[0], xm[1]), fmaxf(xm[2], xm[3]));
-    }
-}
-
-// max over the per-block activation bounds of an eval-mode conv -> the layer's xb slot (one block)
-static __global__ __launch_bounds__(WUNET_THREADS) void xb_reduce_kernel(const float* rows, int n, float* xb)
-{
-    __shared__ float red[WUNET_THREADS];
-    float m = 0.0f;
-    for (int i = threadIdx.x; i < n; i += WUNET_THREADS) m = fmaxf(m, fabsf(rows[i]));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int st = WUNET_THREADS / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + st]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const unsigned u = wunet_fbits(red[0]) & 0x7fffffffu;           // NaN / inf saturate: the scale stays defined
-        xb[0] = u < 0x7f800000u ? red[0] : 3.0e38f;
+        if (threadIdx.x == 0) wunet_atomic_absmax(xrows, fmaxf(fmaxf(xm[0], xm[1]), fmaxf(xm[2], xm[3])));
     }
 }
 

@@ -241,7 +241,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         // conv - the small ones get a pass of act_max_kernel over z.
         const bool ev_need = !training && c->h3 && l.feeds_h3;
         const bool ev_epi = ev_need && (l.first || (l.h3f && !split));
-        float* const xrows = ws + c->stats_off;         // (eval: the statistics rows are free)
+        float* const xrows = fslot + (size_t)WUNET_SLOT_FLOATS * i + 4;     // the layer's xb slot (cleared by h3_scales_kernel): blocks fold their maxima into it
         // (eval: a / s of every layer are already there, bn_eval_all_kernel)
         if (l.first) {
             prof_begin(st, "conv_first_kernel<15>", 2.0 * c->B * l.L * l.cout * 15.0, 4.0 * c->B * l.L * (1.0 + l.cout));
@@ -279,8 +279,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         WUNET_CHECK_LAUNCH();
         // 2c. BatchNorm statistics -> scale/shift for the consumers (+ running stats)
         if (ev_epi) {
-            int nrows = l.first ? l.f.grid_x : (int)(((long long)c->B * l.L + 255) / 256) * (l.h3f_mtp / l.h3f_mrep);
-            WUNET_LAUNCH(xb_reduce_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, (const float*)xrows, nrows, fslot + (size_t)WUNET_SLOT_FLOATS * i + 4);
+            // (eval, un-split conv: its epilogue has folded the activation bound into the xb slot; nothing to launch)
         } else if (split) {
             // sum the z-slices (+bias -> z) and reduce the BN statistics; short levels finish BN in the same launch
             const long long pos = (long long)c->B * l.L;

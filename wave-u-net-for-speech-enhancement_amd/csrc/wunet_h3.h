@@ -39,7 +39,8 @@ struct ConvH3Args {
     float* out;                                   // [B][Cout][L] fp32
     float* stats;                                 // nullptr or [Cout][ntiles][2]: sum, sum of squares per 256-position tile
     // eval mode (BatchNorm coefficients known before the conv): ev_a / ev_s = scale / shift of this layer's BatchNorm, xrows
-    // [gridDim.x] receives the block's max |a (v + bias) + s| - the activation bound the consumers' operand scale derives from
+    // (one float, pre-cleared: the layer's xb slot) receives max |a (v + bias) + s| over all blocks by atomic max - the activation
+    // bound the consumers' operand scale derives from
     const float* ev_a; const float* ev_s; float* xrows;
     unsigned long long* trace;                    // nullptr, or [gridDim.x][64] shader-clock stamps of the block's phases (conv_h3d_kernel; tools/conv_trace.py)
     int B, Cout, C8, NCH, L, logL;

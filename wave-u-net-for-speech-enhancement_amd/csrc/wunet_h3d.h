@@ -174,6 +174,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     const int nfs = KT ? A.NFS : 0x7fffffff, tch = nfs / NTG;        // full stages (TG taps of a chunk of 4 channel groups); the tail stages' chunk
     constexpr int NTT = (TAPS + 3) / 4;            // steps of a tail stage
     int stamp = 0;
+    float amax_run = 0.0f;                          // eval mode: the block's running maximum of the activation bound over its work items
     WUNET_H3D_STAMP(stamp) ++stamp;
     if (st_beg < nstage) {
         WUNET_H3D_ISSUE_X(b, l0, (!KT || st_beg < nfs ? st_beg / NTG : tch))
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             float* rp = red + WUNET_WAVES * M_REP * 32;
             if (lane == 0) rp[wave] = amax;
             wunet_wait_lds_barrier();
-            if (tid == 0) A.xrows[v] = fmaxf(fmaxf(rp[0], rp[1]), fmaxf(rp[2], rp[3]));
+            if (tid == 0) amax_run = fmaxf(amax_run, fmaxf(fmaxf(rp[0], rp[1]), fmaxf(rp[2], rp[3])));
         }
         // one statistics row per tile (256 positions): the four waves' sums are added in wave order
         if (A.stats && !split) {
@@ -386,6 +387,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         if (!more) break;
         v += G; tile = ntile; b = nb; l0 = nl0; mt0 = nmt0;
     }
+    if (A.xrows && tid == 0) wunet_atomic_absmax(A.xrows, amax_run);      // ONE atomic per block into the layer's xb slot
 #undef WUNET_H3D_ISSUE_X
 #undef WUNET_H3D_ISSUE_W
 #undef WUNET_H3D_ITEM
