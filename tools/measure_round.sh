@@ -54,11 +54,8 @@ timeout 200 python bench.py --gemm bf16 --no-cpu-baseline --no-extras > $O/bench
 timeout 200 python bench.py --native-rccl --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_eager.json 2>/dev/null
 timeout 200 python bench.py --native-rccl --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_graph.json 2>/dev/null
 timeout 200 python bench.py --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_graph.json 2>/dev/null
-# training soak on two more seeds: final loss after S steps, default split GEMMs against exact fp32
-for seed in 1 2; do for S in 100 300; do for gm in split fp32; do
-  timeout 200 python bench.py --seed $seed --steps $S --warmup 0 --gemm $gm --no-cpu-baseline --no-extras --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('seed $seed steps $S gemm $gm final_loss', d['final_loss'], 'ms', round(d['ms_per_step'],3))"
-done; done; done > $O/training_soak.txt 2>&1
-timeout 300 python bench.py --layers 16 --frame 65536 --batch 32 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_deep16_split.json 2>/dev/null
+# (the training soak - three seeds, 100 / 300 / 600 steps, split against exact fp32 and the summation-order control - is profiles/r3_training_soak.txt,
+#  measured by its own calls: bench.py --seed S --steps N --warmup 0 [--gemm fp32] with WUNET_BENCH_NO_MEDIAN=1)
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o conc -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python $R/bench.py --no-cpu-baseline --no-extras > $O/serial_bench.json 2>/dev/null
