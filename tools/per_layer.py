@@ -1,4 +1,4 @@
-import csv, collections, sys
+import csv, sys
 from oracle import plan
 d=sys.argv[1]; pre=sys.argv[2]
 rows=list(csv.DictReader(open(f'{d}/{pre}_kernel_trace.csv')))
