@@ -1,0 +1,67 @@
+"""CPU checks of the measurement plumbing (no GPU, no timing): the roofline object bench.py builds from per-kernel rows, the PMC
+sections it attaches, the staleness guard of profiles/pmc_traffic.json, and the per-family traffic table over the committed profiles."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def _rows():
+    return [
+        {"kernel": "conv_h3d_kernel<5, 3, 1>", "launches": 16, "ms": 1.6, "flops": 16 * 20.0e9, "bytes": 16 * 175.0e6},
+        {"kernel": "wgrad_h3d_kernel<5, 3>", "launches": 12, "ms": 0.8, "flops": 12 * 15.0e9, "bytes": 12 * 100.0e6},
+        {"kernel": "conv_mfma_kernel<15, 3, 1>", "launches": 8, "ms": 0.1, "flops": 8 * 1.0e9, "bytes": 8 * 1.0e6},
+        {"kernel": "pass_a_kernel<UP>", "launches": 20, "ms": 0.7, "flops": 0.0, "bytes": 2.8e9},
+        {"kernel": "pass_a_kernel<ENC>", "launches": 22, "ms": 0.6, "flops": 0.0, "bytes": 2.6e9},
+        {"kernel": "prep_h3_kernel<3>", "launches": 20, "ms": 0.4, "flops": 0.0, "bytes": 1.9e9},
+    ]
+
+
+def test_roofline_object_of_the_contract():
+    pmc = {"kernels": {"conv_h3d_kernel<5, 3, 1>": {"hbm_bytes_per_launch": 191000000}}, "whole_step_bytes": 18.0e9, "why": "unit test"}
+    r = bench.roofline_of(_rows(), 2, pmc, 6.37e9)
+    assert r["kernel"] == "conv_h3d_kernel<5, 3, 1>" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s"
+    assert r["avg_launch_ms"] == pytest.approx(0.1) and r["achieved"] == pytest.approx(200.0)          # 20 GFLOP in 0.1 ms
+    assert r["peak"] == pytest.approx(2500.0 / 3.0) and r["frac"] == pytest.approx(0.24)               # three f16 passes per product
+    assert r["traffic"] == 191000000 and r["traffic_whole_step"]["ratio"] == pytest.approx(18.0 / 6.37)
+    assert r["launches_per_step"] == 8 and r["mfma_kernels_ms_per_step"] == pytest.approx(1.25)
+    fam = {m["kernel"]: m for m in r["memory_bound_kernels"]}
+    assert set(fam) == {"pass_a_kernel", "prep_h3_kernel"} and fam["pass_a_kernel"]["launches_per_step"] == 21
+    assert fam["pass_a_kernel"]["algorithmic_GBps"] == pytest.approx(5.4e9 / 1.3e-3 / 1e9)
+    assert bench.gemm_peak("conv_h3d_kernel<5, 3, 1, bf16>")[0] == 2500.0 and bench.gemm_peak("conv_mfma_kernel<5, 4, 4>")[0] == 157.3
+    # a kernel the PMC file does not know: traffic null, the reason carried along
+    r2 = bench.roofline_of(_rows(), 2, {"kernels": None, "why": "no pass"}, 6.37e9)
+    assert r2["traffic"] is None and r2["traffic_whole_step"] is None and r2["traffic_source"] == "no pass"
+
+
+def test_pmc_file_sections_and_staleness_guard(monkeypatch):
+    """profiles/pmc_traffic.json: the headline workload at the top, the extras' own PMC passes under `sections`; bench.py only
+    attaches it while its stamp equals the hash of the kernel sources (after a change under csrc/ the file is refused until
+    tools/measure_round.sh + tools/collect_round.py have re-measured it) - checked here with the stamp the file carries."""
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    assert pmc["whole_step_bytes"] > 1.0e10 and any(k.startswith("conv_h3d_kernel<5, 3, 1") for k in pmc["kernels"])
+    assert set(pmc["sections"]) >= {"gemm_fp32", "deep16_bf16"}
+    monkeypatch.setattr(bench, "source_hash", lambda: pmc["source_hash"])
+    assert bench.load_pmc_traffic()["kernels"] is not None
+    for section in ("gemm_fp32", "deep16_bf16"):
+        sub = bench.load_pmc_traffic(section)
+        assert sub["kernels"] is not None and sub["whole_step_bytes"] > 1.0e10, (section, sub.get("why"))
+    assert bench.load_pmc_traffic("no-such-section")["kernels"] is None
+    monkeypatch.setattr(bench, "source_hash", lambda: "0" * 16)
+    stale = bench.load_pmc_traffic()
+    assert stale["kernels"] is None and "stale" in stale["why"]
+
+
+def test_traffic_table_runs_over_the_committed_profiles(tmp_path):
+    line = open(os.path.join(ROOT, "profiles", "r3_bench.json")).read().strip().splitlines()[-1]
+    assert json.loads(line)["roofline"]["top5"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_table.py"), os.path.join(ROOT, "profiles", "r3_bench.json")],
+                         capture_output=True, text=True, check=True).stdout
+    assert "conv_h3d_kernel" in out and "pass_a_kernel" in out and "all kernels" in out
