@@ -44,7 +44,9 @@ print("# issuing / at s_waitcnt or a barrier / issue-stalled on the matrix pipe 
 print("# (the guide: MFMA_BUSY counts cycles per SIMD-instance summed, BUSY_CYCLES per SE/XCD instance: read it as a RELATIVE measure across kernels);")
 print("# mfma/ideal = 16 cycles x SQ_INSTS_VALU_MFMA_MOPS_F16-derived MFMA count / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE/xcds): the share of the chip's")
 print("# matrix-pipe cycles that issued an f16 MFMA.  clock = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / duration.")
-hdr = "%-44s %5s %9s %7s %7s %7s %8s %9s %10s %9s" % ("kernel", "n", "avg_us", "active", "parked", "stalled", "lds_conf", "mfma_busy", "mfma/ideal", "clock_GHz")
+print("# lds_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x GRBM_GUI_ACTIVE / 8): share of the chip's LDS-array cycles in use; valu/mfma = SQ_INSTS_VALU (the MFMAs included)")
+print("# per f16 MFMA; lds/mfma = SQ_INSTS_LDS per f16 MFMA (wave instructions, pass 2 scaled to pass 1's launch count)")
+hdr = "%-44s %5s %9s %7s %7s %7s %8s %9s %10s %9s %8s %9s %8s" % ("kernel", "n", "avg_us", "active", "parked", "stalled", "lds_conf", "mfma_busy", "mfma/ideal", "clock_GHz", "lds_busy", "valu/mfma", "lds/mfma")
 print(hdr)
 rows = sorted(sq, key=lambda k: -d_sq.get(k, 0.0))
 for k in rows:
@@ -61,10 +63,13 @@ for k in rows:
     mfma_cycles = mops / 32.0 * 16.0
     gui_sq = gui * (d_sq.get(k, 0.0) / dur_g) if dur_g > 0 else 0.0      # the SQ pass's own duration scales the cycle budget
     ideal = 4.0 * 256.0 * gui_sq / 8.0
-    print("%-44s %5d %9.1f %7.3f %7.3f %7.3f %8.4f %9.3f %10.3f %9.2f" % (
+    n_mfma = mops / 32.0 * (n_gr.get(k, 0) / max(n_sq[k], 1))          # wave-level MFMA instructions (32 MOPS units each), for pass 2's launches
+    lds_busy = g.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256.0 * gui / 8.0) if gui > 0 else float("nan")
+    print("%-44s %5d %9.1f %7.3f %7.3f %7.3f %8.4f %9.3f %10.3f %9.2f %8.3f %9s %8s" % (
         k[:44], n_sq[k], d_sq[k] / max(n_sq[k], 1) / 1e3, c.get("SQ_ACTIVE_INST_ANY", 0) / wc, c.get("SQ_WAIT_ANY", 0) / wc, c.get("SQ_WAIT_INST_ANY", 0) / wc,
         c.get("SQ_LDS_BANK_CONFLICT", 0) / wc, c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(c.get("SQ_BUSY_CYCLES", 0), 1.0),
-        mfma_cycles / ideal if ideal > 0 else float("nan"), clock))
+        mfma_cycles / ideal if ideal > 0 else float("nan"), clock, lds_busy,
+        "%.2f" % (g.get("SQ_INSTS_VALU", 0) / n_mfma) if n_mfma > 0 else "-", "%.2f" % (g.get("SQ_INSTS_LDS", 0) / n_mfma) if n_mfma > 0 else "-"))
 print("# raw sums of the GRBM pass (per kernel): GRBM_GUI_ACTIVE, GRBM_COUNT, duration_ns")
 for k in rows[:12]:
     g = gr.get(k, {})
