@@ -212,6 +212,7 @@ typedef char* wunet_lds_t;
 inline wunet_lds_t wunet_lds_addr(const void* p) { return (char*)p; }
 inline int wunet_uniform(int v) { return v; }
 inline void wunet_dma16a(const void* g, wunet_lds_t lds_wave_base) { wunet_dma16(g, lds_wave_base); }
+inline void wunet_dma16s(const void* sbase, unsigned voff, wunet_lds_t lds_wave_base) { wunet_dma16((const char*)sbase + voff, lds_wave_base); }
 inline void wunet_dma16a_if(int pred, const void* g, wunet_lds_t lds_wave_base) { if (pred) wunet_dma16(g, lds_wave_base); }
 inline void wunet_wait_lds_barrier_if(int pred) { if (pred) emu::block_barrier(); }
 inline void wunet_wait_dma_barrier() { emu::block_barrier(); }

@@ -242,7 +242,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
                                     ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2,
-                                    split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st, nullptr, nullptr,
+                                    split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st, ws + l.gzp, nullptr, nullptr,
                                     nullptr, c->bf, l.h3d_ntt);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();

@@ -132,6 +132,20 @@ __device__ __forceinline__ void wunet_dma16a(const void* g, wunet_lds_t lds_wave
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
 }
+// The same DMA in the scalar-base form: address = sbase (wave-uniform, an SGPR pair) + voff (32-bit unsigned byte offset per lane).
+// A piece then costs NO per-lane 64-bit address arithmetic: the per-lane part is one stage-invariant register per piece, the part
+// that moves with the stage / tile is a scalar add (conv_h3d_kernel: ~9 VALU per piece before - 330 VALU beside the 180 MFMAs of a
+// stage, 3.0 VALU per MFMA by the SQ counters, the kernels with the most VALU per MFMA the least busy matrix pipes).
+__device__ __forceinline__ void wunet_dma16s(const void* sbase, unsigned voff, wunet_lds_t lds_wave_base)
+{
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_wave_base);
+    const unsigned long long b = (unsigned long long)(__UINTPTR_TYPE__)sbase;
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    const unsigned long long sb = ((unsigned long long)bhi << 32) | blo;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sb), "s"(lds) : "memory");
+}
 // ... skipped when the wave-uniform pred is 0, by a branch INSIDE the asm statement: the caller's code stays one basic block, so
 // hipcc can schedule the address arithmetic of the pieces between the MFMAs around them
 __device__ __forceinline__ void wunet_dma16a_if(int pred, const void* g, wunet_lds_t lds_wave_base)

@@ -71,6 +71,8 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 d.w = (l.h3f || l.h3d) ? params[4 * i] : nullptr; d.wn = (unsigned)((size_t)l.cout * l.cin * l.taps);
                 d.gamma = params[4 * i + 2]; d.beta = params[4 * i + 3]; d.C = l.cout;
                 d.sqrtn = sqrtf((float)((double)c->B * l.Lt));
+                d.zp0 = l.h3f ? ws + l.xzp : nullptr;
+                d.zp1 = (l.h3d && training && save_for_backward) ? ws + l.gzp : nullptr;      // (the backward segment only exists then)
                 any = any || l.h3f;
             }
             T.wmax = ws + c->wmax_off; T.slots = ws + c->fslot_off; T.training = training ? 1 : 0;
@@ -263,7 +265,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
-                                    l.cin, l.h3f_nch, l.L, st, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf, l.h3f_ntt);
+                                    l.cin, l.h3f_nch, l.L, st, ws + l.xzp, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf, l.h3f_ntt);
             if (rc) return rc;
         } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;

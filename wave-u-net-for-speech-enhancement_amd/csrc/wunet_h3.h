@@ -33,6 +33,10 @@ static __device__ __attribute__((aligned(16))) const unsigned wunet_zero16[8] = 
 struct ConvH3Args {
     const wunet_half* xh; const wunet_half* xl;   // [B][C8][L][8]
     const wunet_half* wh; const wunet_half* wl;   // packed
+    // conv_h3d_kernel addresses its DMA pieces as SGPR base + unsigned 32-bit offset: the lo plane / lo pack must lie xdelta / wdelta
+    // bytes BEHIND the hi one (< 4 GiB), and zpad - 16 zero bytes that pieces outside the tensor fetch - behind both planes
+    unsigned xdelta, wdelta;
+    const void* zpad;
     const float* bias;                            // [Cout] or nullptr
     const float* sc;                              // nullptr or {scale, 1/scale} of the input: the result is multiplied by sc[1]
     const float* sc2;                             // nullptr or {scale, 1/scale} of the packed weights: ... and by sc2[1]

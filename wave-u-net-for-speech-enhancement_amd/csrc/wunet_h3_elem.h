@@ -20,6 +20,7 @@ struct ScaleDesc {
     const float* w; unsigned wn;                  // conv weight (nullptr: no split pack of this layer)
     const float* gamma; const float* beta; int C; // BatchNorm affine parameters of the layer
     float sqrtn;                                  // sqrt(B * L)
+    float* zp0; float* zp1;                       // nullptr or the 16-byte zero pads behind the layer's split conv input / split g_z: cleared here
 };
 struct ScaleTable { ScaleDesc d[WUNET_MAX_CONV_LAYERS]; float* wmax; float* slots; int training; };
 
@@ -53,6 +54,11 @@ static __global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTa
             __syncthreads();
         }
         if (tid == 0) T.slots[blockIdx.y * WUNET_SLOT_FLOATS + 4] = red[0];
+        // the zero pads the DMA pieces outside a tensor fetch (conv_h3d_kernel: halo beyond an item, channel groups beyond C8)
+        if (tid < 4) {
+            if (d.zp0) d.zp0[tid] = 0.0f;
+            if (d.zp1) d.zp1[tid] = 0.0f;
+        }
     }
 }
 

@@ -21,6 +21,10 @@
 // MFMAs on the same accumulator instead of hipcc's back-to-back chains.
 #pragma once
 #include "wunet_h3.h"
+// WUNET_ABL: ablation builds of tools/conv_ablation.sh (parts of the kernel compiled out, bits listed there); 0 in the product
+#ifndef WUNET_ABL
+#define WUNET_ABL 0
+#endif
 
 
 // (no tail stages in the two shapes at the register limit: they would spill)
@@ -46,14 +50,15 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
     const int L = A.L;
-    const wunet_half* const zero = reinterpret_cast<const wunet_half*>(wunet_zero16);
 
     // ---- per-thread source descriptors of its DMA pieces (independent of the work item).  A DMA instruction of a wave writes one
     // RUN of 64 consecutive pieces; the runs of the x image ([plane][4 groups][COLS, de-interleaved]: RP runs per plane) are dealt
     // so that the plane of an instruction is a compile-time constant: instruction it < NPL*XF covers runs 4 (it % XF) + wave of
     // plane it / XF, the XR left-over runs of every plane share one last instruction (wave -> plane wave / XR, run 4 XF + wave % XR).
     // Piece p of a plane is (channel group c8 = p / COLS, column col = 4 (w % Q4) + w / Q4 with w = p % COLS - the de-interleave).
-    // Kept per piece: xoffb = bytes from the first sample of the tile in the chunk's first channel group; per thread, one bit per
+    // Kept per piece: xoffb = bytes from 8 samples in front of the tile's first sample in the chunk's first channel group of the hi
+    // plane (never negative: the DMA takes an SGPR base + an unsigned 32-bit offset per lane; the lo plane lies A.xdelta bytes behind
+    // the hi plane and is part of the offset); per thread, one bit per
     // piece: m_live (the wave has a run in the shared instruction), m_lo / m_hi (the piece is left / right halo: outside the item
     // for the first / last tile of an item, always for NSEG > 1), m_pl (plane of the shared instruction); c8pk / segpk = the
     // piece's channel group (2 bits) / item of the tile (4 bits).
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         if (it == NPL * XF) { pl = wave / (XR ? XR : 1); run = 4 * XF + wave % (XR ? XR : 1); live = wave < XR * NPL; xrun = run; }
         const int p = run * 64 + lane, c8 = p / COLS, w = p % COLS;
         const int col = 4 * (w % Q4) + w / Q4, seg = col / SW, lrel = col - seg * SW - 8;
-        xoffb[it] = ((seg * A.C8 + c8) * L + lrel) * 16;
+        xoffb[it] = ((seg * A.C8 + c8) * L + lrel + 8) * 16 + (NPL > 1 && (pl & 1) ? (int)A.xdelta : 0);
         m_live |= (unsigned)live << it;
         m_lo |= (unsigned)(lrel < 0) << it;
         m_hi |= (unsigned)(lrel >= LSEG) << it;
@@ -80,17 +85,13 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         c8pk |= (unsigned)c8 << (2 * it);
         segpk |= (unsigned long long)seg << (4 * it);
     }
-    // W sub-tile [hi|lo][M_REP][TG][64 pieces]: piece f = tid + 256 it; woff = halfs from the stage's first piece in the pack | lo << 30
-    int woff[WIT];
-#pragma unroll
-    for (int it = 0; it < WIT; ++it) {
-        const int f = tid + it * WUNET_THREADS;
-        const int which = f / (M_REP * WPM), r = f % (M_REP * WPM), mt = r / WPM, p = r % WPM;
-        woff[it] = ((mt * A.NS * TG * 64 + p) * 8) | (which << 30);
-    }
+    // W sub-tile [hi|lo][M_REP][TG][64 pieces]: per (plane, m-tile) a contiguous run of TG * 64 = 320 pieces in the pack and in the LDS
+    // image alike - one DMA instruction of all four waves (pieces 0 .. 255, lane offset 16 tid) plus one of a single wave (pieces
+    // 256 .. 319); the run's start is a scalar.  Two per-lane offsets serve every W piece of the kernel.
+    static_assert(WPM == 320, "W run = 256 + 64 pieces");
+    const unsigned wo_all = (unsigned)tid * 16u, wo_rest = (256u + (unsigned)lane) * 16u;
     const wunet_lds_t xs_a = wunet_lds_addr(xs), ws_a = wunet_lds_addr(ws);
     const int wave_u = wunet_uniform(wave);
-    const long long zero_a = (long long)reinterpret_cast<size_t>(zero);
     // pieces of the tile that lie inside the tensor: bit per piece.  Halo pieces of an item's first / last tile (every halo piece
     // for NSEG > 1: each item of the tile carries its own zero padding), items beyond the batch, channel groups beyond C8 (only the
     // last chunk can have them: the test is skipped elsewhere)
@@ -108,40 +109,32 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
                 if ((CH_) * 4 + (int)((c8pk >> (2 * it)) & 3) >= A.C8) OUT_ &= ~(1u << it);                       \
         }                                                                                                         \
     }
-    // (the descriptors are made opaque at every use: hipcc would otherwise hoist one 64-bit address per piece out of the stage
-    // loop and carry 34 more registers through the MFMA phase)
-#define WUNET_H3D_X_PIECE(IT_, VALID_, XH_, XL_)                                                                  \
+    // A piece: SGPR base of the tile (+ stage) + the piece's stage-invariant 32-bit offset; a piece outside the tensor takes the offset of
+    // the operand's 16-byte zero pad (A.zpad, behind both planes) instead.  No 64-bit address per lane, nothing for hipcc to hoist.
+#define WUNET_H3D_X_PIECE(IT_, VALID_, BASE_, ZSEL_)                                                              \
     {                                                                                                             \
-        int o_ = xoffb[IT_];                                                                                      \
-        wunet_opaque(o_);                                                                                         \
-        const bool lo_ = (IT_) < NPL * XF ? (IT_) / XF != 0 : ((m_pl >> (IT_)) & 1) != 0;                         \
-        const long long real_ = (lo_ ? (XL_) : (XH_)) + o_;                                                       \
-        const long long a_ = ((VALID_) >> (IT_)) & 1 ? real_ : zero_a;                                            \
+        const unsigned o_ = (((VALID_) >> (IT_)) & 1) && !(WUNET_ABL & 128) ? (unsigned)xoffb[IT_] : (ZSEL_);                             \
         const int run_ = (IT_) < NPL * XF ? 4 * ((IT_) % XF) + wave_u : wunet_uniform(xrun);                      \
         const int pl_ = (IT_) < NPL * XF ? (IT_) / XF : wunet_uniform((m_pl >> (IT_)) & 1);                       \
-        wunet_dma16a(reinterpret_cast<const void*>(a_), xs_a + (pl_ * 4 * COLS + run_ * 64) * 16);                \
+        wunet_dma16s(BASE_, o_, xs_a + (pl_ * 4 * COLS + run_ * 64) * 16);                                        \
     }
 #define WUNET_H3D_ISSUE_X(B_, L0_, CH_)                                                                           \
     {                                                                                                             \
-        const long long boff_ = (long long)((((size_t)(B_) * A.C8 + (CH_) * 4) * L + (L0_)) * 16);                \
-        const long long xh_ = (long long)reinterpret_cast<size_t>(A.xh) + boff_, xl_ = (long long)reinterpret_cast<size_t>(A.xl) + boff_; \
+        const char* const base_ = reinterpret_cast<const char*>(A.xh) + (long long)((((size_t)(B_) * A.C8 + (CH_) * 4) * L + (L0_)) * 16) - 128; \
+        const unsigned zsel_ = (unsigned)(reinterpret_cast<const char*>(A.zpad) - base_);                         \
         WUNET_H3D_VALID(B_, L0_, CH_, valid_)                                                                     \
-        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
-            if (it < NPL * XF) WUNET_H3D_X_PIECE(it, valid_, xh_, xl_)                                            \
-            else if ((m_live >> it) & 1) WUNET_H3D_X_PIECE(it, valid_, xh_, xl_)                                  \
+        if (!(WUNET_ABL & (2 | 8))) _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
+            if (it < NPL * XF) WUNET_H3D_X_PIECE(it, valid_, base_, zsel_)                                        \
+            else if ((m_live >> it) & 1) WUNET_H3D_X_PIECE(it, valid_, base_, zsel_)                              \
         }                                                                                                         \
     }
 #define WUNET_H3D_ISSUE_W(MT0_, ST_)                                                                              \
     {                                                                                                             \
-        const long long boff_ = (long long)((((size_t)(MT0_) * A.NS + (ST_)) * TG * 64) * 16);                    \
-        const long long wh_ = (long long)reinterpret_cast<size_t>(A.wh) + boff_, wl_ = (long long)reinterpret_cast<size_t>(A.wl) + boff_; \
-        _Pragma("unroll") for (int it = 0; it < WIT; ++it) {                                                      \
-            if ((it + 1) * WUNET_THREADS <= WP || tid + it * WUNET_THREADS < WP) {                                \
-                int m_ = woff[it];                                                                                \
-                wunet_opaque(m_);                                                                                 \
-                const long long a_ = ((m_ >> 30) & 1 ? wl_ : wh_) + (long long)(m_ & 0x3fffffff) * 2;             \
-                wunet_dma16a(reinterpret_cast<const void*>(a_), ws_a + (it * WUNET_THREADS + wave_u * 64) * 16);  \
-            }                                                                                                     \
+        const char* const base_ = reinterpret_cast<const char*>(A.wh) + (long long)((((size_t)(MT0_) * A.NS + (ST_)) * TG * 64) * 16); \
+        if (!(WUNET_ABL & (2 | 16))) _Pragma("unroll") for (int sub = 0; sub < NPL * M_REP; ++sub) {                                           \
+            const char* const run_ = (WUNET_ABL & 256) ? reinterpret_cast<const char*>(A.wh) : base_ + (long long)(sub % M_REP) * A.NS * (TG * 64 * 16) + (sub >= M_REP ? (long long)A.wdelta : 0LL); \
+            wunet_dma16s(run_, wo_all, ws_a + (sub * WPM + wave_u * 64) * 16);                                    \
+            if (wave_u == (sub & 3)) wunet_dma16s(run_, wo_rest, ws_a + (sub * WPM + 256) * 16);                  \
         }                                                                                                         \
     }
     // work item v -> (position tile, row block): the row blocks of one tile on ONE XCD (they share its x tile in that L2);
@@ -206,6 +199,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             const int nst = last ? st_beg : st + 1, nch = (!KT || nst < nfs) ? nst / NTG : tch;
             const bool x_next = has_next && (last || nch != ch);
             wunet_setprio(0);
+            if (WUNET_ABL & 32) __syncthreads(); else
             wunet_wait_dma_barrier();             // this stage's x tile and W sub-tile have landed (every wave waited for its own pieces)
             WUNET_H3D_STAMP(stamp) ++stamp;
             wunet_setprio(3);
@@ -231,7 +225,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         if (!BF) al[BUF_][mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + (TL_)) * 64 * 8 + aoff);                     \
     }
 #define WUNET_H3D_PASS(WHICH_, BUF_, TL_)                                                                         \
-    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
+    if (!(WUNET_ABL & 1)) _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
             if (BF) { if ((WHICH_) == 2) acc[mt][nt] = wunet_mfma16b(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]); } \
             else if ((WHICH_) == 0) acc[mt][nt] = wunet_mfma16h(al[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);       \
@@ -332,7 +326,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
                 if (STATS_) { s1[r] += vv; s2[r] = fmaf(vv, vv, s2[r]); }                                                    \
                 o[nt] = vv + bv;                                                                                  \
             }                                                                                                     \
-            if (!(GUARD_) || (co < A.Cout && bo < A.B)) {                                                         \
+            if ((!(GUARD_) || (co < A.Cout && bo < A.B)) && (!(WUNET_ABL & 4) || o[0] == 123.456f)) {                                                         \
                 wunet_st4(prow + (size_t)(mt * 16 + r) * L, o);                                                   \
                 if (EVAL_) {                                                                                      \
                     const float ea = eas[mt][r], es = ess[mt][r];                                                 \

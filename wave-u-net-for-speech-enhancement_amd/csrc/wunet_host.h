@@ -83,8 +83,8 @@ struct LayerPlan {
     int skip_from;                // decoder layer: > 0 = its skip half is written by the operand pass of encoder-side layer skip_from
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps, h3w_tp;   // weight gradient uses wgrad_h3_kernel
     int feeds_h3;                 // the layer's activation is the (or a) source of a conv input that exists in the split layout
-    size_t xh, xl;                // split activated input (float offsets)
-    size_t gzh, gzl;              // split scaled g_z (float offsets)
+    size_t xh, xl, xzp;           // split activated input (float offsets): hi plane, lo plane right behind it, then 16 zero bytes (DMA pad)
+    size_t gzh, gzl, gzp;         // split scaled g_z (float offsets), likewise
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
 };
 
@@ -133,8 +133,8 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
                  int B, int C, int L, hipStream_t st, int bf = 0);
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
-                   int kch, int nch, int L, hipStream_t st, const float* ev_a = nullptr, const float* ev_s = nullptr, float* xrows = nullptr,
-                   int bf = 0, int ntt = 0);
+                   int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a = nullptr, const float* ev_s = nullptr,
+                   float* xrows = nullptr, int bf = 0, int ntt = 0);
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
                     const float* sc, const float* sc2, float* part, int B, hipStream_t st, int bf = 0);
 int launch_backward_packs(wunet_ctx* c, const float* const* params, float* ws, hipStream_t st);

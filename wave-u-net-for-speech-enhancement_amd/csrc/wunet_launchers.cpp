@@ -110,14 +110,21 @@ int h3_grid_cap()
 }
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
-                   int kch, int nch, int L, hipStream_t st, const float* ev_a, const float* ev_s, float* xrows, int bf, int ntt)
+                   int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a, const float* ev_s, float* xrows, int bf, int ntt)
 {
+    // conv_h3d_kernel addresses its DMA pieces as SGPR base + unsigned 32-bit offset: lo plane / lo pack behind the hi one, the zero pad
+    // behind both, everything within 4 GiB of the hi arrays
+    const long long xd = bf ? 0 : (const char*)xl - (const char*)xh, wd = bf ? 0 : (const char*)wl - (const char*)wh;
+    const long long zd = (const char*)zpad - (const char*)xh, plane = (long long)B * ((kch + 7) / 8) * L * 16;
+    if (!zpad || xd < 0 || wd < 0 || xd >= (1LL << 31) || wd >= (1LL << 31) || zd < plane + xd || zd + 256 >= (1LL << 32))
+        return fail(WUNET_E_ARG, "conv_h3d operand layout: lo plane / lo pack / zero pad must lie behind the hi array within 4 GiB");
     char pname[96];
     const double posn = (double)B * L;
     ConvH3Args a{};
     a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.sc2 = sc2; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
     a.ev_a = ev_a; a.ev_s = ev_s; a.xrows = xrows;
+    a.xdelta = (unsigned)xd; a.wdelta = (unsigned)wd; a.zpad = zpad;
     const int nseg = L >= 256 ? 1 : 256 / L, nstage = h3_stage_count(kch, taps, ntt);
     a.NS = nstage; a.NFS = ntt ? (a.C8 / 4) * (taps / 5) : nstage;
     const int ksplit = (nstage + sps - 1) / sps;

@@ -195,32 +195,45 @@ int op_split_check(int B, int Cin, int Cout, int L, int K, bool backward)
 }
 
 // fp32 [B][C][L] -> scaled hi / lo in the split layout; slot: 8 floats, [0..1] receive {scale, 1/scale}, [4] the measured max
-int op_split_operand(const float* x, int B, int C, int L, DevBuf& hi, DevBuf& lo, float* slot, const float* ones, const float* zeros, hipStream_t st)
+// (one allocation: hi plane | lo plane | 64 zero bytes - the layout conv_h3d_kernel's DMA addressing wants, launch_conv_h3)
+struct SplitBuf {
+    DevBuf buf;
+    size_t plane = 0;
+    wunet_half* h() const { return buf.h(); }
+    wunet_half* l() const { return reinterpret_cast<wunet_half*>(static_cast<char*>(buf.p) + plane); }
+    const void* zpad() const { return static_cast<char*>(buf.p) + 2 * plane; }
+};
+int op_split_operand(const float* x, int B, int C, int L, SplitBuf& sb, float* slot, const float* ones, const float* zeros, hipStream_t st)
 {
     const int c8 = (C + 7) / 8;
-    if (!hi.alloc((size_t)B * c8 * L * 16) || !lo.alloc((size_t)B * c8 * L * 16)) return fail(WUNET_E_RUNTIME, "hipMalloc");
+    sb.plane = (size_t)B * c8 * L * 16;
+    if (!sb.buf.alloc(2 * sb.plane + 64)) return fail(WUNET_E_RUNTIME, "hipMalloc");
+    hipMemsetAsync(static_cast<char*>(sb.buf.p) + 2 * sb.plane, 0, 64, st);
     hipMemsetAsync(slot, 0, WUNET_SLOT_FLOATS * sizeof(float), st);
     const size_t n4 = (size_t)B * C * L / 4;
     size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
     if (blocks > 2048) blocks = 2048;
     WUNET_LAUNCH(act_max_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, ones, zeros, C, ilog2(L), n4, slot + 4);
-    return launch_split(x, hi.h(), lo.h(), nullptr, slot + 4, nullptr, slot, B, C, L, st);
+    return launch_split(x, sb.h(), sb.l(), nullptr, slot + 4, nullptr, slot, B, C, L, st);
 }
 
 int op_conv_split_common(const float* x, const float* w, const float* bias, float* out, int B, int kch, int rows, int Cout, int Cin,
                          int L, int K, int transposed, hipStream_t st)
 {
     const H3ConvPlan p = plan_h3_conv(B, L, rows, kch, K, transposed ? "WUNET_H3D_ORDER" : "WUNET_H3_ORDER");
-    DevBuf xh, xl, wh, wl, misc, part;
+    SplitBuf xs;
+    DevBuf wpk, misc, part;
     const size_t wh_halfs = (size_t)p.mtp * p.nch * K * 512, nout = (size_t)B * rows * L;
     // misc: slot of x (8 floats) | slot of w (8) | partial weight maxima | ones (kch) | zeros (kch)
-    if (!wh.alloc(wh_halfs * 2) || !wl.alloc(wh_halfs * 2) || !misc.alloc((16 + WUNET_WMAX_PARTS + 2 * (size_t)kch) * sizeof(float)) ||
+    if (!wpk.alloc(wh_halfs * 4) || !misc.alloc((16 + WUNET_WMAX_PARTS + 2 * (size_t)kch) * sizeof(float)) ||
         (p.ksplit > 1 && !part.alloc((size_t)p.ksplit * nout * sizeof(float))))
         return fail(WUNET_E_RUNTIME, "hipMalloc");
     float* xslot = misc.f(), *wslot = misc.f() + 8, *wmax = misc.f() + 16, *oz = misc.f() + 16 + WUNET_WMAX_PARTS;
     WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz, (size_t)kch, 1.0f);
     WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz + kch, (size_t)kch, 0.0f);
-    int rc = op_split_operand(x, B, kch, L, xh, xl, xslot, oz, oz + kch, st);
+    wunet_half* const whp = wpk.h();
+    wunet_half* const wlp = wpk.h() + wh_halfs;
+    int rc = op_split_operand(x, B, kch, L, xs, xslot, oz, oz + kch, st);
     if (rc) return rc;
     {
         ScaleTable T{};
@@ -229,14 +242,14 @@ int op_conv_split_common(const float* x, const float* w, const float* bias, floa
         WUNET_LAUNCH(h3_scales_kernel, dim3(WUNET_WMAX_PARTS, 1), dim3(WUNET_THREADS), 0, st, T);
         PackH3Table tab{};
         PackH3Desc& d = tab.d[0];
-        d.w = w; d.hi = wh.h(); d.lo = wl.h(); d.Cout = Cout; d.Cin = Cin; d.taps = K; d.rows = rows; d.kch = kch; d.mtiles = p.mtp; d.nch = p.nch;
+        d.w = w; d.hi = whp; d.lo = wlp; d.Cout = Cout; d.Cin = Cin; d.taps = K; d.rows = rows; d.kch = kch; d.mtiles = p.mtp; d.nch = p.nch;
         d.ntt = p.ntt; d.nfull = ((kch + 7) / 8) / 4; d.ns = h3_stage_count(kch, K, p.ntt);
         d.transposed = transposed; d.wmax = wmax; d.wsc = wslot + 2;
         WUNET_LAUNCH(pack_h3_kernel, dim3(64, 1), dim3(WUNET_THREADS), 0, st, tab);
     }
     const bool split = p.ksplit > 1;
-    rc = launch_conv_h3(K, p.mrep, p.mtp, p.sps, xh.h(), xl.h(), wh.h(), wl.h(), split ? nullptr : bias, xslot, wslot + 2,
-                        split ? part.f() : out, nullptr, B, rows, kch, p.nch, L, st, nullptr, nullptr, nullptr, 0, p.ntt);
+    rc = launch_conv_h3(K, p.mrep, p.mtp, p.sps, xs.h(), xs.l(), whp, wlp, split ? nullptr : bias, xslot, wslot + 2,
+                        split ? part.f() : out, nullptr, B, rows, kch, p.nch, L, st, xs.zpad(), nullptr, nullptr, nullptr, 0, p.ntt);
     if (!rc && split) {
         size_t blocks = (nout + WUNET_THREADS - 1) / WUNET_THREADS;
         if (blocks > 2048) blocks = 2048;
@@ -270,7 +283,8 @@ int wunet_op_conv1d_wgrad_split(const float* gz, const float* x, float* dw, int 
     LayerPlan l{};
     l.cin = Cin; l.cout = Cout; l.taps = K; l.L = L; l.logL = ilog2(L);
     plan_h3_wgrad(l, B);
-    DevBuf xh, xl, gh, gl, misc, part;
+    SplitBuf xs, gs;
+    DevBuf misc, part;
     const int cmax = Cin > Cout ? Cin : Cout;
     // misc: slot of g_z | slot of x | ones | zeros
     if (!misc.alloc((16 + 2 * (size_t)cmax) * sizeof(float)) || !part.alloc((size_t)l.h3w_ksplit * h3w_part_stride(l) * sizeof(float)))
@@ -278,9 +292,9 @@ int wunet_op_conv1d_wgrad_split(const float* gz, const float* x, float* dw, int 
     float* gslot = misc.f(), *xslot = misc.f() + 8, *oz = misc.f() + 16;
     WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz, (size_t)cmax, 1.0f);
     WUNET_LAUNCH(fill_kernel, dim3(4), dim3(WUNET_THREADS), 0, st, oz + cmax, (size_t)cmax, 0.0f);
-    int rc = op_split_operand(gz, B, Cout, L, gh, gl, gslot, oz, oz + cmax, st);
-    if (!rc) rc = op_split_operand(x, B, Cin, L, xh, xl, xslot, oz, oz + cmax, st);
-    if (!rc) rc = launch_wgrad_h3(l, xh.h(), xl.h(), gh.h(), gl.h(), gslot, xslot, part.f(), B, st);
+    int rc = op_split_operand(gz, B, Cout, L, gs, gslot, oz, oz + cmax, st);
+    if (!rc) rc = op_split_operand(x, B, Cin, L, xs, xslot, oz, oz + cmax, st);
+    if (!rc) rc = launch_wgrad_h3(l, xs.h(), xs.l(), gs.h(), gs.l(), gslot, xslot, part.f(), B, st);
     if (!rc) {
         WgradH3ReduceArgs ra{};
         ra.part = part.f(); ra.part_stride = h3w_part_stride(l); ra.splits = l.h3w_ksplit; ra.dw = dw;

@@ -367,11 +367,12 @@ void layout_workspace(wunet_ctx* c)
     size_t wfh = 0;
     for (int i = 0; i < c->NL; ++i) {
         LayerPlan& l = c->ly[i];
-        l.xh = l.xl = 0; l.h3f_wpk = l.h3d_wpk = 0;
+        l.xh = l.xl = l.xzp = 0; l.h3f_wpk = l.h3d_wpk = 0;
         if (l.h3f) {
             const int c8 = (l.cin + 7) / 8;
             l.xh = off; off += align64((size_t)B * c8 * l.L * 4);
             l.xl = off; off += align64((size_t)B * c8 * l.L * 4);
+            l.xzp = off; off += 64;
             l.h3f_wpk = wfh; wfh += (size_t)l.h3f_mtp * l.h3f_nch * l.taps * 512;
         }
     }
@@ -431,6 +432,7 @@ void layout_workspace(wunet_ctx* c)
         l.h3d_wpk = wbh; wbh += (size_t)l.h3d_mtp * l.h3d_nch * l.taps * 512;
         l.gzh = off; off += align64((size_t)B * c8 * l.L * 4);      // per layer: the side stream reads it late
         l.gzl = off; off += align64((size_t)B * c8 * l.L * 4);
+        l.gzp = off; off += 64;
     }
     c->h3_wb_halfs = wbh;
     c->h3_wb_hi = off; off += align64((wbh + 1) / 2);

@@ -15,7 +15,7 @@ C ABI of include/wunet_hip.h.  There is no CPU fallback: calling the module on a
 import torch
 import torch.nn as nn
 
-from .engine import default_engine
+from .engine import FlatGrads, default_engine
 from .plan import conv_layer_shapes
 
 
@@ -40,10 +40,10 @@ class _WaveUNetFn(torch.autograd.Function):
             raise NotImplementedError("gradient w.r.t. the waveform input is not part of the reference hot path "
                                       "(encoder[0] needs no data gradient); detach the input")
         engine = owner._engine()
-        params = [p.detach() for p in params]
         running, nbt = owner._wunet_buffers()
         training = owner.training
-        out, ws = engine.forward(owner.n_layers, owner.channels_interval, noisy.detach(), params, running, nbt,
+        # (grad mode is off inside Function.forward and the engine only takes addresses: no detached copies of the 102 parameters)
+        out, ws = engine.forward(owner.n_layers, owner.channels_interval, noisy, params, running, nbt,
                                  training, with_backward=need_grad and training)
         ctx.owner = owner
         ctx.training = training
@@ -62,16 +62,20 @@ class _WaveUNetFn(torch.autograd.Function):
         owner = ctx.owner
         noisy, out, *params = ctx.saved_tensors
         engine = owner._engine()
-        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.float32, device=noisy.device)
-        grads, off = [], 0
-        for p in params:
-            grads.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=noisy.device)
         sync = owner.grad_sync
         if sync is None:
+            # the kernels only need addresses (flat buffer + offsets): enqueue first, cut the 102 views autograd wants while the GPU runs
+            offsets, off = [], 0
+            for n in sizes:
+                offsets.append(off)
+                off += n
             engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out.contiguous(),
-                            ctx.ws, grads)
+                            ctx.ws, FlatGrads(flat, offsets))
+            grads = [g.view(p.shape) for g, p in zip(flat.split(sizes), params)]
         else:
+            grads = [g.view(p.shape) for g, p in zip(flat.split(sizes), params)]
             sync.run(engine, owner, noisy, params, out, grad_out.contiguous(), ctx.ws, grads, flat)
         owner.last_flat_grad = flat
         ctx.ws = None
@@ -98,21 +102,35 @@ class Model(nn.Module):
     def _engine(self):
         return self._engine_override if self._engine_override is not None else default_engine()
 
-    def _blocks(self):
-        return [lv.main for lv in self.encoder] + [self.middle] + [lv.main for lv in self.decoder]
+    # The 102 parameters / 75 buffers in the C ABI's order, read through the modules' own dicts on every call (nothing cached: a
+    # replaced sub-module or parameter is seen) - through nn.Module.__getattr__ and Sequential indexing the two lists cost the host
+    # ~0.3 ms per forward, which a loop that synchronises every step (trainer/trainer.py:40) pays in full as GPU idle time.
+    def _leaves(self):
+        m = self._modules
+        seqs = [lv._modules["main"]._modules for lv in m["encoder"]._modules.values()]
+        seqs.append(m["middle"]._modules)
+        seqs += [lv._modules["main"]._modules for lv in m["decoder"]._modules.values()]
+        return [(q["0"], q["1"]) for q in seqs]
+
+    @staticmethod
+    def _param(mod, name):
+        p = mod._parameters.get(name)
+        return p if p is not None else getattr(mod, name)         # (nn.DataParallel replicas keep plain tensors as attributes)
 
     def _wunet_params(self):
-        ps = []
-        for blk in self._blocks():
-            ps += [blk[0].weight, blk[0].bias, blk[1].weight, blk[1].bias]
-        ps += [self.out[0].weight, self.out[0].bias]
+        ps, P = [], self._param
+        for conv, bn in self._leaves():
+            ps += [P(conv, "weight"), P(conv, "bias"), P(bn, "weight"), P(bn, "bias")]
+        head = self._modules["out"]._modules["0"]
+        ps += [P(head, "weight"), P(head, "bias")]
         return ps
 
     def _wunet_buffers(self):
         running, nbt = [], []
-        for blk in self._blocks():
-            running += [blk[1].running_mean, blk[1].running_var]
-            nbt.append(blk[1].num_batches_tracked)
+        for _, bn in self._leaves():
+            b = bn._buffers
+            running += [b["running_mean"], b["running_var"]]
+            nbt.append(b["num_batches_tracked"])
         return running, nbt
 
     def forward(self, input):
