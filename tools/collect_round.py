@@ -16,9 +16,16 @@ for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.
                  ("bench_deep16_split.json", "bench_deep16_split.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
-                 ("fwd_kernel_stats.csv", "forward_kernel_stats.csv")):
-    if os.path.exists(os.path.join(F, src)):
-        shutil.copy(os.path.join(F, src), os.path.join(P, f"{tag}_{dst}"))
+                 ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"),
+                 ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt")):
+    if not os.path.exists(os.path.join(F, src)):
+        continue
+    if src.endswith(".json"):           # the bench line only (RCCL prints its banner into the same stream on some paths)
+        lines = [ln for ln in open(os.path.join(F, src)).read().splitlines() if ln.startswith("{")]
+        if lines:
+            open(os.path.join(P, f"{tag}_{dst}"), "w").write(lines[-1] + "\n")
+            continue
+    shutil.copy(os.path.join(F, src), os.path.join(P, f"{tag}_{dst}"))
 # the PMC runs execute 3 steps (1 warm-up + 2): launches / 3 = launches per step.  FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE
 # under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section): doubled.
 def lib_name(k):

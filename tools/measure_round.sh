@@ -63,4 +63,10 @@ WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-for
 # keep what collect_round.py needs, drop the bulky traces
 for d in conc serial fwd; do f=$(find $O/$d -name "${d}_kernel_stats.csv" | head -1); cp $f $O/${d}_kernel_stats.csv; g=$(find $O/$d -name "${d}_kernel_trace.csv" | head -1); [ "$d" = serial ] && cp $g $O/serial_kernel_trace.csv; rm -rf $O/$d; done
 python $R/tools/timeline.py $O/serial_kernel_trace.csv > $O/step_timeline.txt 2>/dev/null
+# host side of a step (back to back / synchronised every step), the conv kernel with parts compiled out (tools/conv_ablation.sh build first, in the
+# container), the LDS-DMA issue microbench (hipcc --offload-arch=gfx950 -O3 -o tools/microbench/_dma_issue tools/microbench/dma_issue.hip)
+cd $R
+timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu > $O/host_phases.txt
+ls tools/_lib_abl2.so > /dev/null 2>&1 && timeout 300 bash tools/conv_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/conv_ablation.txt $O/conv_ablation.txt
+[ -x tools/microbench/_dma_issue ] && timeout 60 tools/microbench/_dma_issue > $O/dma_issue_microbench.txt
 ls -la $O
