@@ -170,6 +170,44 @@ def test_fused_adam_device_step_counter_and_grad_scale(emu_engine):
     assert int(fa._dev[0][0]) == 4 and int(fa.state[pa[0]]["step"]) == 4
 
 
+def test_fused_adam_shared_step_counter_is_invisible(emu_engine):
+    """Inside FusedAdam the parameters of a group share ONE host step counter object (102 scalar increments per step were a tenth of
+    the host's time per step); outside it must look like torch.optim.Adam's per-parameter counters: state_dict() hands out separate
+    tensors, a parameter that has no gradient in a step does not advance (and leaves the shared counter), torch's Adam takes over."""
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    torch.manual_seed(5)
+    base = [torch.randn(6, 4), torch.randn(11), torch.randn(3)]
+    pa = [torch.nn.Parameter(t.clone()) for t in base]
+    pb = [torch.nn.Parameter(t.clone()) for t in base]
+    fa = optim_mod.FusedAdam(pa, lr=1e-2)
+    fa._engine_override = emu_engine
+    tb = torch.optim.Adam(pb, lr=1e-2)
+    for k in range(5):
+        g = torch.Generator().manual_seed(k)
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            gr = torch.randn(a.shape, generator=g)
+            skip = i == 1 and k in (2, 3)                    # the middle parameter sits two steps out
+            a.grad = None if skip else gr.clone()
+            b.grad = None if skip else gr.clone()
+        fa.step(); tb.step()
+    assert [int(fa.state[p]["step"]) for p in pa] == [int(tb.state[p]["step"]) for p in pb] == [5, 3, 5]
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max() < 1e-6
+    assert fa.state[pa[0]]["step"] is fa.state[pa[2]]["step"] and fa.state[pa[1]]["step"] is not fa.state[pa[0]]["step"]
+    sd = fa.state_dict()
+    steps = [sd["state"][i]["step"] for i in range(3)]
+    assert steps[0] is not steps[2] and steps[0].data_ptr() != steps[2].data_ptr()
+    steps[0] += 10                                           # a holder of the checkpoint cannot move the live counters
+    assert int(fa.state[pa[0]]["step"]) == 5
+    # (counters that disagree: one launch per distinct count - checked above against torch's Adam; the device-resident counter of
+    # the graph-capturable form is ONE per group and refuses)
+    fd = optim_mod.FusedAdam(pa, lr=1e-2, device_step=True)
+    fd._engine_override = emu_engine
+    fd.load_state_dict(fa.state_dict())
+    with pytest.raises(RuntimeError, match="share the step count"):
+        fd.step()
+
+
 def test_second_backward_and_input_gradient_are_refused_with_a_message(emu_engine):
     m = _model(2, 4, emu_engine).train()
     x = torch.zeros(2, 1, 64)

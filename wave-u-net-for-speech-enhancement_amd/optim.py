@@ -84,11 +84,12 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
-            ps, gs, ms, vs, steps = [], [], [], [], []
+            ps, gs, ms, vs, steps, skipped = [], [], [], [], [], []
             state = self.state
             for p in group["params"]:
                 g = p.grad
                 if g is None:
+                    skipped.append(p)
                     continue
                 st = state[p]
                 if len(st) == 0:
@@ -97,30 +98,42 @@ class FusedAdam(torch.optim.Optimizer):
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 ps.append(p); gs.append(g if g.is_contiguous() else g.contiguous())
                 ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"]); steps.append(st["step"])
-            step = None
-            if ps:
-                # The host-side step counters.  torch.optim.Adam's layout wants one "step" tensor per parameter; 102 scalar `+= 1`
-                # (or one _foreach_add_ over 102 CPU scalars) cost the host 0.2 - 0.3 ms per step, so the parameters of a group
-                # share ONE tensor object while their counts agree (state_dict() and checkpoints look the same: the value per key).
-                s0 = steps[0]
-                if all(t is s0 for t in steps):
-                    s0 += 1
-                else:
-                    vals = {float(t.item()) for t in steps}
-                    if len(vals) != 1:
-                        raise RuntimeError("FusedAdam: parameters of one group must share the step count")
-                    s0 = torch.tensor(vals.pop() + 1.0, dtype=torch.float32)
-                    for p in ps:
-                        state[p]["step"] = s0
-                step = int(s0.item())
-            if ps:
-                b1, b2 = group["betas"]
-                step_dev = hyper_dev = None
-                if self.device_step:
-                    if gi not in self._dev:          # (outside any capture: the first eager step creates and seeds it)
-                        self._dev[gi] = (torch.full((), step - 1, dtype=torch.int64, device=ps[0].device),
-                                         torch.zeros(2, dtype=torch.float32, device=ps[0].device))
-                    step_dev, hyper_dev = self._dev[gi]
-                self._engine().adam_step(ps, gs, ms, vs, group["lr"], b1, b2, group["eps"], step, self.grad_scale,
-                                         step_dev, hyper_dev)
+            if not ps:
+                continue
+            # The host-side step counters.  torch.optim.Adam's layout wants one "step" tensor per parameter; 102 scalar `+= 1`
+            # (or one _foreach_add_ over 102 CPU scalars) cost the host 0.2 - 0.3 ms per step, so parameters whose counts agree
+            # share ONE tensor object (state_dict() and checkpoints look the same: the value per key).
+            s0 = steps[0]
+            for p in skipped:               # a parameter without a gradient does not step (torch.optim.Adam): it leaves the shared counter
+                st = state.get(p)
+                if st and st.get("step") is s0:
+                    st["step"] = s0.clone()
+            if all(t is s0 for t in steps):
+                s0 += 1
+                launches = [(int(s0.item()), ps, gs, ms, vs)]
+            else:
+                # counts that differ (a parameter that sat out some steps, a checkpoint just loaded): one launch per distinct count -
+                # a launch has one bias correction - and one shared counter per such sub-group from here on
+                by = {}
+                for k, t in enumerate(steps):
+                    by.setdefault(float(t.item()), []).append(k)
+                launches = []
+                for v, idx in by.items():
+                    sv = torch.tensor(v + 1.0, dtype=torch.float32)
+                    for k in idx:
+                        state[ps[k]]["step"] = sv
+                    launches.append((int(v) + 1, [ps[k] for k in idx], [gs[k] for k in idx], [ms[k] for k in idx], [vs[k] for k in idx]))
+            b1, b2 = group["betas"]
+            step_dev = hyper_dev = None
+            if self.device_step:
+                if len(launches) != 1:
+                    raise RuntimeError("FusedAdam(device_step=True): the parameters of one group must share the step count "
+                                       "(the group has ONE counter on the device)")
+                step = launches[0][0]
+                if gi not in self._dev:              # (outside any capture: the first eager step creates and seeds it)
+                    self._dev[gi] = (torch.full((), step - 1, dtype=torch.int64, device=ps[0].device),
+                                     torch.zeros(2, dtype=torch.float32, device=ps[0].device))
+                step_dev, hyper_dev = self._dev[gi]
+            for step, lp, lg, lm, lv in launches:
+                self._engine().adam_step(lp, lg, lm, lv, group["lr"], b1, b2, group["eps"], step, self.grad_scale, step_dev, hyper_dev)
         return loss
