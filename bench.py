@@ -263,8 +263,8 @@ def main():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the training step as ONE captured hipGraph (torch.cuda.CUDAGraph over forward + loss + backward + "
                          "fused Adam with its device-side step counter; SURVEY.md section 8 f2).  auto = off: measured on MI355X / "
-                         "ROCm 7.0 the replay of the ~270-node graph costs the host as much as the eager launches (4.9 ms) and the "
-                         "GPU 4 %% more (6.65 vs 6.41 ms per step), so the headline stays eager")
+                         "ROCm 7.0 the replay of the ~230-node graph costs the host 0.8 ms instead of 2.2 but the GPU 10 %% more "
+                         "(5.84 vs 5.32 ms per step, profiles/r3_bench_graph.json), so the headline stays eager")
     ap.add_argument("--native-rccl", action="store_true",
                     help="the gradient all-reduce through the library's own RCCL entry (include/wunet_hip.h wunet_comm_*: enqueued on the "
                          "backward's streams, capturable with --graph on) instead of torch.distributed's process group; at --gpus 1 the "

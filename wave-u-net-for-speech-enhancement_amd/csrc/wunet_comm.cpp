@@ -42,7 +42,11 @@ Api& api()
                 a.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
                 if (a.lib) break;
             }
-        if (!a.lib) { a.why = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return; }
+        if (!a.lib) {
+            const char* e = dlerror();             // (a second dlerror() returns null: it clears the message)
+            a.why = std::string("librccl.so not found: ") + (e ? e : "no loader message");
+            return;
+        }
         a.GetUniqueId = (int (*)(UniqueId*))dlsym(a.lib, "ncclGetUniqueId");
         a.CommInitRank = (int (*)(Comm*, int, UniqueId, int))dlsym(a.lib, "ncclCommInitRank");
         a.CommDestroy = (int (*)(Comm))dlsym(a.lib, "ncclCommDestroy");
