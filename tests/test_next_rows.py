@@ -208,6 +208,29 @@ def test_fused_adam_shared_step_counter_is_invisible(emu_engine):
         fd.step()
 
 
+def test_batched_validation_names_the_offending_tensor(emu_engine):
+    """The host validates the 102 parameters / 75 buffers of a call in one pass (engine._require_all); a bad tensor is still refused
+    before anything is enqueued, by name and index."""
+    pkg = importlib.import_module(PKG_NAME)
+    engine_mod = importlib.import_module(PKG_NAME + ".engine")
+    m = pkg.Model(n_layers=2, channels_interval=4)
+    m._engine_override = emu_engine
+    torch.manual_seed(7)
+    x = torch.randn(2, 1, 64)
+    m(x)                                                            # (fine as built)
+    m.encoder[1].main[0].weight.data = m.encoder[1].main[0].weight.data.double()
+    with pytest.raises(engine_mod.WunetError, match=r"param\[4\]: expected float32"):
+        m(x)
+    m.encoder[1].main[0].weight.data = m.encoder[1].main[0].weight.data.float().transpose(0, 1).contiguous().transpose(0, 1)
+    with pytest.raises(engine_mod.WunetError, match=r"param\[4\]: tensor must be contiguous"):
+        m(x)
+    # a replaced parameter is seen by the next call (the lists are read from the modules every time, nothing is cached)
+    m.encoder[1].main[0].weight = torch.nn.Parameter(torch.randn(m.encoder[1].main[0].weight.shape))
+    before = m(x)
+    m.encoder[1].main[0].weight = torch.nn.Parameter(torch.randn(m.encoder[1].main[0].weight.shape))
+    assert not torch.equal(m(x), before)
+
+
 def test_second_backward_and_input_gradient_are_refused_with_a_message(emu_engine):
     m = _model(2, 4, emu_engine).train()
     x = torch.zeros(2, 1, 64)
