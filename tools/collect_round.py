@@ -16,7 +16,7 @@ for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.
                  ("bench_deep16_split.json", "bench_deep16_split.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
-                 ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"),
+                 ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"), ("next_rows_bench.txt", "next_rows_bench.txt"),
                  ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt")):
     if not os.path.exists(os.path.join(F, src)):
         continue
