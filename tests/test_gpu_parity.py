@@ -393,6 +393,12 @@ def test_chunked_inference_vs_reference_loop(pkg, dev):
     with torch.no_grad():
         ref = torch.cat([torch_port.forward(tsd, c, n, ci, False) for c in torch.split(padded, sl, dim=-1)], dim=-1)[:, :, :T]
     assert (out - ref).abs().max().item() < TOL
+    # to_host=True: slabs copied into one pinned host buffer (here two slabs and a ragged third), the same numbers as the slabs
+    # run one after the other on the device
+    host = inference.enhance(m, mix.to(dev), sample_length=sl, max_batch=2, to_host=True)
+    assert host.device.type == "cpu" and host.shape == (1, 1, T)
+    assert torch.equal(host, inference.enhance(m, mix.to(dev), sample_length=sl, max_batch=2).cpu())
+    assert (host - ref).abs().max().item() < TOL
 
 
 @pytest.mark.parametrize("n,ci,B,T,loss", [(1, 24, 1, 64, "mse"), (3, 10, 3, 512, "smooth_l1"), (5, 7, 5, 2048, "l1"),

@@ -36,6 +36,7 @@ def test_chunked_inference_equals_reference_loop(emu_engine):
     rng = np.random.default_rng(5)
     mix = rng.standard_normal((1, 1, T)).astype(np.float32)
     out = inference.enhance(m, torch.from_numpy(mix), sample_length=sl, max_batch=3).numpy()
+    assert torch.equal(inference.enhance(m, torch.from_numpy(mix), sample_length=sl, max_batch=3, to_host=True), torch.from_numpy(out))
     assert out.shape == (1, 1, T)
     padded = np.concatenate([mix, np.zeros((1, 1, (-T) % sl), np.float32)], axis=-1)
     ref = []
