@@ -201,15 +201,56 @@ __device__ __forceinline__ wunet_f4 wunet_sum_splits4(const float* p, int ksplit
     return v;
 }
 
+// xb (eval mode, a layer that feeds split operands; nullptr otherwise): the layer's activation bound max |a_c z + s_c| is folded into
+// *xb by ONE atomic max per block (a / s are bn_eval_all_kernel's) - act_max_kernel's pass over z in the launch that writes z.
 static __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(BnFwdArgs A, const float* part, int ksplit,
                                                                         size_t split_stride, float* z, int B, int L, int logL,
-                                                                        float* stats_rows, int Lt)
+                                                                        float* stats_rows, int Lt, float* xb)
 {
     __shared__ double red[2 * WUNET_THREADS];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float bias = A.bias[c];
     double s1 = 0.0, s2 = 0.0;
     const int total = B * L;
+    if (!A.training) {
+        // eval: z = sum of the splits + bias; no statistics (the coefficients come from the running ones, already finalised)
+        const float ea = xb ? A.a[c] : 0.0f, es = xb ? A.s[c] : 0.0f;
+        float m = 0.0f, m2 = 0.0f;
+        if ((L & 3) == 0) {
+            const int total4 = total >> 2;
+            const int per = (total4 + gridDim.y - 1) / gridDim.y;
+            const int beg = blockIdx.y * per, end = beg + per < total4 ? beg + per : total4;
+            for (int p4 = beg + tid; p4 < end; p4 += WUNET_THREADS) {
+                const int p = p4 << 2;
+                const int b = p >> logL, l = p & (L - 1);
+                const size_t off = ((size_t)b * A.C + c) * L + l;
+                const wunet_f4 v = wunet_sum_splits4(part + off, ksplit, split_stride);
+                wunet_f4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = v[j] + bias;
+                    m = fmaxf(m, fabsf(ea * o[j] + es));
+                }
+                wunet_st4(z + off, o);
+            }
+        } else {
+            const int per = (total + gridDim.y - 1) / gridDim.y;
+            const int beg = blockIdx.y * per, end = beg + per < total ? beg + per : total;
+            for (int p = beg + tid; p < end; p += WUNET_THREADS) {
+                const int b = p >> logL, l = p & (L - 1);
+                const size_t off = ((size_t)b * A.C + c) * L + l;
+                float v = 0.0f;
+                for (int k = 0; k < ksplit; ++k) v += part[(size_t)k * split_stride + off];
+                z[off] = v + bias;
+                m = fmaxf(m, fabsf(ea * (v + bias) + es));
+            }
+        }
+        if (xb) {
+            block_max2(m, m2, red);
+            if (tid == 0) wunet_atomic_absmax(xb, m);
+        }
+        return;
+    }
     if ((L & 3) == 0) {
         // four samples per thread (16-byte loads and stores); every level of >= 4 samples
         const int total4 = total >> 2;
@@ -252,8 +293,7 @@ static __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(Bn
             float* st = stats_rows + ((size_t)c * gridDim.y + blockIdx.y) * 2;
             st[0] = (float)s1;
             st[1] = (float)s2;
-        } else if (A.training) bn_finalize_core(A, c, s1, s2);
-        else bn_eval_core(A, c);
+        } else bn_finalize_core(A, c, s1, s2);
     }
 }
 

@@ -290,7 +290,8 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             if (rs > 64) rs = 64;
             b.rows = rs;
             WUNET_LAUNCH(conv_reduce_bn_kernel, dim3(l.cout, rs), dim3(WUNET_THREADS), 0, st, b, (const float*)(ws + c->spart_off),
-                         tiny ? 1 : l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off, l.Lt);
+                         tiny ? 1 : l.f.ksplit, (size_t)c->B * l.cout * l.L, ws + l.z, c->B, l.L, l.logL, ws + c->stats_off, l.Lt,
+                         ev_need ? xrows : (float*)nullptr);
             if (rs > 1 && training) {
                 WUNET_CHECK_LAUNCH();
                 WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
@@ -299,7 +300,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_LAUNCH(bn_finalize_fwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
         }
         WUNET_CHECK_LAUNCH();
-        if (ev_need && !ev_epi) {
+        if (ev_need && !ev_epi && !split) {          // (a split layer's reduce kernel has taken the bound)
             const size_t n4 = (size_t)c->B * l.cout * l.L / 4;
             size_t blocks = (n4 + WUNET_THREADS * 4 - 1) / (WUNET_THREADS * 4);
             if (blocks > 2048) blocks = 2048;
