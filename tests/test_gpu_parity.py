@@ -960,3 +960,68 @@ def test_bf16_mode_vs_reference_under_autocast(pkg, dev, n, ci, B, T, mode):
     if ge_ref < 0.5:
         assert ge <= ge_ref, (ge, ge_ref)
     assert oe > 1e-4                       # really the bf16 arithmetic
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# world size 2 on the hardware: two processes share the one GPU of the box and run the real HIP backward with GradSync's bucketed
+# schedule; the collective goes through gloo (RCCL refuses two ranks on one device), so this covers everything of the N > 1 path
+# but the transport - the transport itself is test_rccl_* / test_native_rccl_* at world size 1 and the driver's 8-GPU run.
+def _dp2_worker(rank, world, port, tmpdir):
+    import os
+    import sys
+    import torch.distributed as dist
+    from conftest import PKG_NAME as PKG, ROOT
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import plan as oplan
+        pkg_ = importlib.import_module(PKG)
+        parallel = importlib.import_module(PKG + ".parallel")
+        dev_ = torch.device("cuda:0")
+        n, ci, B, T = 5, 8, 4, 1024
+        m = pkg_.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in oplan.golden_state(n, ci, 0).items()})
+        m.to(dev_).train()
+        m.grad_sync = parallel.GradSync(n_buckets=3)
+        noisy, clean = oplan.golden_batch(B * world, T, 0)
+        sl = slice(rank * B, (rank + 1) * B)
+        out = m(torch.from_numpy(noisy[sl].copy()).to(dev_))
+        pkg_.mse_loss()(torch.from_numpy(clean[sl].copy()).to(dev_), out).backward()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), **{k: p.grad.cpu().numpy() for k, p in m.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_grad_sync_world2_on_the_hardware(tmp_path):
+    """SURVEY.md section 8(c)(v) on the MI355X: two ranks (two processes on the one GPU, gloo as the transport) each back-propagate
+    their shard through the HIP kernels with parallel.GradSync's bucketed, overlapped schedule; both end with the MEAN of the
+    per-shard float64-oracle gradients (per-shard BatchNorm, trainer/base_trainer.py:26-27)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 2
+    mp.spawn(_dp2_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    n, ci, B, T = 5, 8, 4, 1024
+    noisy, clean = plan.golden_batch(B * world, T, 0)
+    refs = [c_oracle.step(plan.golden_state(n, ci, 0), noisy[r * B:(r + 1) * B], clean[r * B:(r + 1) * B], n, ci, True, "mse",
+                          precision="f64")["grads"] for r in range(world)]
+    got = [np.load(str(tmp_path / f"rank{r}.npz")) for r in range(world)]
+    for k in refs[0]:
+        key = k
+        avg = sum(ref[k].astype(np.float64) for ref in refs) / world
+        assert np.array_equal(got[0][key], got[1][key]), k             # both ranks hold the same averaged gradient, bit for bit
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            assert np.all(got[0][key] == 0.0)
+            continue
+        scale = max(np.abs(avg).max(), 1e-6)
+        assert np.abs(got[0][key] - avg).max() < 1e-3 * scale + 1e-6, (k, np.abs(got[0][key] - avg).max(), scale)
+    whole = c_oracle.step(plan.golden_state(n, ci, 0), noisy, clean, n, ci, True, "mse", precision="f64")["grads"]
+    k = "encoder.1.main.0.weight"
+    avg = sum(ref[k].astype(np.float64) for ref in refs) / world
+    assert np.abs(whole[k] - avg).max() > 1e-3 * np.abs(avg).max()      # (one shard of the whole batch is a different number)
