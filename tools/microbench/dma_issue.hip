@@ -8,6 +8,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o _dma_issue dma_issue.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -71,14 +72,16 @@ __global__ __launch_bounds__(256, 2) void stage_loop(const char* src, size_t per
     if (tid == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    // optional: <stages> <only: 0 MFMAs, 1 DMAs hot, 2 DMAs cold, 3 burst hot, 4 burst cold> - one long launch for tools/power_probe.sh
+    const int arg_stages = argc > 1 ? atoi(argv[1]) : 0, only = argc > 2 ? atoi(argv[2]) : -1;
     const size_t GiB = 1ull << 30;
     char* src; float* out; unsigned long long* ticks;
     hipMalloc(&src, GiB + (1 << 20)); hipMemset(src, 0, GiB + (1 << 20));
     hipMalloc(&out, 64); hipMalloc(&ticks, 512 * 8);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    const int blocks = 512, stages = 200;
+    const int blocks = 512, stages = arg_stages > 0 ? arg_stages : 200;
     unsigned long long h[512];
     printf("512 blocks x 256 threads, 2 per CU; per stage and wave 180 MFMAs (16x16x32 f16), 16 LDS-DMA instructions (64 KB per block)\n");
     auto run = [&](const char* what, auto kern, bool cold) {
@@ -99,13 +102,13 @@ int main()
     hipFuncSetAttribute((const void*)stage_loop<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipFuncSetAttribute((const void*)stage_loop<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     hipFuncSetAttribute((const void*)stage_loop<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    run("MFMAs only (DMA columns do not apply)", stage_loop<0>, false);
-    run("DMAs only, hot (L2)", stage_loop<1>, false);
-    run("DMAs only, cold (HBM)", stage_loop<1>, true);
-    run("burst of 16 DMAs + MFMAs, hot", stage_loop<2>, false);
-    run("burst of 16 DMAs + MFMAs, cold", stage_loop<2>, true);
-    run("one DMA per 11 MFMAs, hot", stage_loop<3>, false);
-    run("one DMA per 11 MFMAs, cold", stage_loop<3>, true);
+    if (only < 0 || only == 0) run("MFMAs only (DMA columns do not apply)", stage_loop<0>, false);
+    if (only < 0 || only == 1) run("DMAs only, hot (L2)", stage_loop<1>, false);
+    if (only < 0 || only == 2) run("DMAs only, cold (HBM)", stage_loop<1>, true);
+    if (only < 0 || only == 3) run("burst of 16 DMAs + MFMAs, hot", stage_loop<2>, false);
+    if (only < 0 || only == 4) run("burst of 16 DMAs + MFMAs, cold", stage_loop<2>, true);
+    if (only < 0) run("one DMA per 11 MFMAs, hot", stage_loop<3>, false);
+    if (only < 0) run("one DMA per 11 MFMAs, cold", stage_loop<3>, true);
     if (hipDeviceSynchronize() != hipSuccess) { printf("FAILED\n"); return 1; }
     return 0;
 }
