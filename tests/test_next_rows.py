@@ -169,6 +169,17 @@ def test_fused_adam_device_step_counter_and_grad_scale(emu_engine):
     for a, b in zip(pa, pb):
         assert torch.equal(a, b)
     assert int(fa._dev[0][0]) == 4 and int(fa.state[pa[0]]["step"]) == 4
+    # the step writes through raw pointers: autograd's version counters are told (a stale graph fails loudly)
+    w = torch.nn.Parameter(torch.ones(3))
+    fo = optim_mod.FusedAdam([w], lr=1e-2)
+    fo._engine_override = emu_engine
+    y = (w * w).sum()                        # saves w for its backward
+    w.grad = torch.ones(3)
+    v0 = w._version
+    fo.step()
+    assert w._version > v0
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        y.backward()
 
 
 def test_fused_adam_shared_step_counter_is_invisible(emu_engine):

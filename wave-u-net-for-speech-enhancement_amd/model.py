@@ -45,6 +45,8 @@ class _WaveUNetFn(torch.autograd.Function):
         # (grad mode is off inside Function.forward and the engine only takes addresses: no detached copies of the 102 parameters)
         out, ws = engine.forward(owner.n_layers, owner.channels_interval, noisy, params, running, nbt,
                                  training, with_backward=need_grad and training)
+        if training:                      # the kernels updated the running statistics through raw pointers: tell the version counters
+            torch.autograd.graph.increment_version(running + nbt)
         ctx.owner = owner
         ctx.training = training
         ctx.ws = ws if need_grad else None

@@ -136,4 +136,8 @@ class FusedAdam(torch.optim.Optimizer):
                 step_dev, hyper_dev = self._dev[gi]
             for step, lp, lg, lm, lv in launches:
                 self._engine().adam_step(lp, lg, lm, lv, group["lr"], b1, b2, group["eps"], step, self.grad_scale, step_dev, hyper_dev)
+                # the kernel wrote p, exp_avg and exp_avg_sq through raw pointers: tell autograd's version counters, as every in-place
+                # torch op would (a graph that saved a parameter and is back-propagated after this step must fail loudly, and anything
+                # keyed on `_version` must see the change)
+                torch.autograd.graph.increment_version(lp + lm + lv)
         return loss
