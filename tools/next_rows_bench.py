@@ -83,7 +83,7 @@ same = float((a - b).abs().max())
 t0 = time.perf_counter(); batched(); torch.cuda.synchronize(); tb = time.perf_counter() - t0
 t0 = time.perf_counter(); reference_loop(); torch.cuda.synchronize(); tl = time.perf_counter() - t0
 print("f3  enhancing a %d-sample recording (%d chunks of 16384), result on the host; max |batched - loop| = %.1e" % (T, nch, same))
-print("    inference.enhance (slabs of 256 chunks, async copies into one pinned buffer) %.1f ms = %.0f chunks/s" % (tb * 1e3, nch / tb))
+print("    inference.enhance (equal slabs of <= 256 chunks, async copies into one pinned buffer) %.1f ms = %.0f chunks/s" % (tb * 1e3, nch / tb))
 print("    the reference's loop (batch 1, a copy per chunk)   %.1f ms = %.0f chunks/s   -> %.1fx" % (tl * 1e3, nch / tl, tl / tb))
 
 # ---------------------------------------------------------------- f4

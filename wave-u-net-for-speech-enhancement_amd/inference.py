@@ -25,6 +25,9 @@ def enhance(model, mixture, sample_length=16384, max_batch=256, to_host=False):
         mixture = torch.cat([mixture, torch.zeros(1, 1, pad, device=mixture.device, dtype=mixture.dtype)], dim=-1)
     chunks = mixture.reshape(-1, 1, sample_length)               # == torch.split(..., sample_length, dim=-1) stacked
     n = chunks.shape[0]
+    # equal slabs (586 chunks -> 196 + 196 + 194, not 256 + 256 + 74): no small ragged forward at the end, one context size
+    nslab = (n + max_batch - 1) // max_batch
+    max_batch = (n + nslab - 1) // nslab
     if to_host and mixture.is_cuda:
         host = torch.empty(n, 1, sample_length, dtype=mixture.dtype, pin_memory=True)
         for i in range(0, n, max_batch):
