@@ -36,6 +36,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: dense f16/bf16 MFMA
 # ceiling in algorithmic (fp32) flops is a third of the f16 peak
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBS = 8000.0
+SUSTAINED_F16_MFMA_TFLOPS = 2070.0     # measured here: a register-only MFMA loop, clock settled at the board's power limit (profiles/r3_power_probe.txt)
 
 
 def net_flops_bytes(n, ci, frame):
@@ -144,7 +145,14 @@ def roofline_of(rows, nprof, pmc, step_algorithmic_bytes):
         whole = {"hbm_bytes_per_step": pmc["whole_step_bytes"], "algorithmic_bytes_per_step": step_algorithmic_bytes,
                  "ratio": pmc["whole_step_bytes"] / step_algorithmic_bytes}
     return {"bound": "mfma", "kernel": top["kernel"], "achieved": achieved, "peak": peak, "peak_note": peak_note,
-            "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+            "unit": "TFLOP/s", "frac": achieved / peak,
+            # beside the data-sheet roof: what a register-only loop of the same MFMA sustains on this part once the clock has settled at
+            # the board's power limit (profiles/r3_power_probe.txt: 2.07 PFLOP/s f16 at 1316 W and 2.05 GHz) - f16 kernels only
+            "power_limited_peak": (None if "_h3" not in top["kernel"] else
+                                   {"value": SUSTAINED_F16_MFMA_TFLOPS / (1.0 if "bf16" in top["kernel"] else 3.0), "unit": "TFLOP/s",
+                                    "frac": achieved / (SUSTAINED_F16_MFMA_TFLOPS / (1.0 if "bf16" in top["kernel"] else 3.0)),
+                                    "source": "tools/power_probe.sh, profiles/r3_power_probe.txt"}),
+            "traffic": traffic,
             "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
             "traffic_whole_step": whole,
             "algorithmic_bytes_per_launch": top["bytes"] / top["launches"],
