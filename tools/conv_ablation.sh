@@ -4,12 +4,13 @@
 # builds are garbage by construction - only their times mean anything.
 #   bits: 1 no MFMAs   2 no DMA at all   4 no output stores   8 no x-tile DMA   16 no W DMA   32 no vmcnt wait at the top of a stage
 #         128 every x piece from the 16-byte zero pad (cache hit)   256 every W run from the first run of the pack (cache hit)
+#         512 two MFMA passes instead of three (the W_lo x_hi products dropped: what a pass costs)
 #   tools/conv_ablation.sh build      (container: hipcc)  ->  tools/_lib_abl<bits>.so  (git-ignored, shipped by gpurun)
 #   tools/conv_ablation.sh run        (GPU box)           ->  gpurun_out/conv_ablation.txt
 set -e
 cd "$(dirname "$0")/.."
 CS=wave-u-net-for-speech-enhancement_amd/csrc
-VARIANTS="1 2 4 6 8 16 32 128 384"
+VARIANTS="1 2 4 6 8 16 32 128 384 512"
 if [ "$1" = build ]; then
     make -C $CS -j8 > /dev/null
     for a in $VARIANTS; do
@@ -37,7 +38,7 @@ for a in 0 $VARIANTS; do
     python tools/conv_bench.py --min-l 256 2>/dev/null | grep -E "^(enc|dec|total)" | awk '{ if ($1 == "total") print "total", $4; else print $1, $6 }' > /tmp/abl_$a.txt
 done
 python - >> $OUT <<'P'
-cols = [0, 1, 2, 4, 6, 8, 16, 32, 128, 384]
+cols = [0, 1, 2, 4, 6, 8, 16, 32, 128, 384, 512]
 rows = {}
 order = []
 for a in cols:
@@ -48,6 +49,6 @@ for a in cols:
 for k in order:
     print("%-6s" % k + "".join(" %7.1f" % rows[k].get(a, float("nan")) for a in cols))
 print("0 the product kernel; 1 no MFMAs (staging + stores only); 2 no DMA; 4 no stores; 6 neither (MFMAs, LDS reads, barriers only); 8 no x DMA;")
-print("16 no W DMA; 32 no vmcnt wait at the stage top; 128 x pieces from a cached page (W real); 384 x and W from cached pages")
+print("16 no W DMA; 32 no vmcnt wait at the stage top; 128 x pieces from a cached page (W real); 384 x and W from cached pages; 512 two MFMA passes instead of three")
 P
 cat $OUT

@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         if (!BF) al[BUF_][mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + (TL_)) * 64 * 8 + aoff);                     \
     }
 #define WUNET_H3D_PASS(WHICH_, BUF_, TL_)                                                                         \
-    if (!(WUNET_ABL & 1)) _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
+    if (!(WUNET_ABL & 1) && !((WUNET_ABL & 512) && (WHICH_) == 0)) _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
             if (BF) { if ((WHICH_) == 2) acc[mt][nt] = wunet_mfma16b(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]); } \
             else if ((WHICH_) == 0) acc[mt][nt] = wunet_mfma16h(al[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);       \
