@@ -17,6 +17,14 @@ class WunetError(RuntimeError):
     pass
 
 
+def bump_versions(tensors):
+    """Tell autograd's version counters that a kernel wrote these tensors through raw pointers (what every in-place torch op does
+    by itself).  torch >= 2.1 has the call; older ones are left as they were."""
+    inc = getattr(torch.autograd.graph, "increment_version", None)
+    if inc is not None:
+        inc(tensors)
+
+
 class FlatGrads:
     """The gradient tensors of `Engine.backward` as ONE flat fp32 buffer + the element offset of every parameter in it."""
 

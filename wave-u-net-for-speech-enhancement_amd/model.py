@@ -15,7 +15,7 @@ C ABI of include/wunet_hip.h.  There is no CPU fallback: calling the module on a
 import torch
 import torch.nn as nn
 
-from .engine import FlatGrads, default_engine
+from .engine import FlatGrads, bump_versions as _bump_versions, default_engine
 from .plan import conv_layer_shapes
 
 
@@ -46,7 +46,7 @@ class _WaveUNetFn(torch.autograd.Function):
         out, ws = engine.forward(owner.n_layers, owner.channels_interval, noisy, params, running, nbt,
                                  training, with_backward=need_grad and training)
         if training:                      # the kernels updated the running statistics through raw pointers: tell the version counters
-            torch.autograd.graph.increment_version(running + nbt)
+            _bump_versions(running + nbt)
         ctx.owner = owner
         ctx.training = training
         ctx.ws = ws if need_grad else None

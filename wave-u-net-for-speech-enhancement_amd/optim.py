@@ -15,7 +15,7 @@ the host-side `state["step"]` is kept in step by `advance_host_step()` after eve
 """
 import torch
 
-from .engine import default_engine
+from .engine import bump_versions as _bump_versions, default_engine
 
 _ADAM_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False,
                       fused=None, decoupled_weight_decay=False)
@@ -139,5 +139,5 @@ class FusedAdam(torch.optim.Optimizer):
                 # the kernel wrote p, exp_avg and exp_avg_sq through raw pointers: tell autograd's version counters, as every in-place
                 # torch op would (a graph that saved a parameter and is back-propagated after this step must fail loudly, and anything
                 # keyed on `_version` must see the change)
-                torch.autograd.graph.increment_version(lp + lm + lv)
+                _bump_versions(lp + lm + lv)
         return loss
