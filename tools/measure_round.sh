@@ -66,7 +66,7 @@ python $R/tools/timeline.py $O/serial_kernel_trace.csv > $O/step_timeline.txt 2>
 # host side of a step (back to back / synchronised every step), the conv kernel with parts compiled out (tools/conv_ablation.sh build first, in the
 # container), the LDS-DMA issue microbench (hipcc --offload-arch=gfx950 -O3 -o tools/microbench/_dma_issue tools/microbench/dma_issue.hip)
 cd $R
-timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu > $O/host_phases.txt
+{ echo "tools/host_phases.py on one box, with the C++ marshalling extension (torch_ext/wunet_torch.cpp, the default when built) and with WUNET_NO_TORCH_EXT=1 (ctypes)"; timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu; WUNET_NO_TORCH_EXT=1 timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu | sed 's/^/ctypes: /'; } > $O/host_phases.txt
 timeout 300 python tools/next_rows_bench.py 2>/dev/null | grep -v amdgpu > $O/next_rows_bench.txt       # f1 / f3 / f4 of SURVEY.md section 8(f)
 ls tools/_lib_abl2.so > /dev/null 2>&1 && timeout 300 bash tools/conv_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/conv_ablation.txt $O/conv_ablation.txt
 [ -x tools/microbench/_dma_issue ] && timeout 60 tools/microbench/_dma_issue > $O/dma_issue_microbench.txt

@@ -32,6 +32,24 @@ class FlatGrads:
         self.flat, self.offsets = flat, offsets
 
 
+def _load_torch_ext():
+    """The optional C++ marshalling layer (torch_ext/wunet_torch.cpp, built by __graft_entry__.build()); None when it is not there or
+    when WUNET_LIB_PATH selects another build of the library (the extension is linked to csrc/libwunet_hip.so)."""
+    if os.environ.get("WUNET_LIB_PATH") or os.environ.get("WUNET_NO_TORCH_EXT"):
+        return None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "torch_ext", "_wunet_torch.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_wunet_torch", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    except Exception:                    # noqa: BLE001 - optional: a stale build (other torch) falls back to ctypes
+        return None
+
+
 class Engine:
     """One per process is enough (see `default_engine`).  `lib`/`host_memory` exist so the CPU test
     suite can drive the same host logic against the emulator build with CPU tensors; product code
@@ -49,6 +67,8 @@ class Engine:
         # least-recently-used ones are destroyed beyond MAX_CONTEXTS (variable-length inference would otherwise leak one per shape)
         self._ctx = collections.OrderedDict()
         self._lock = threading.Lock()
+        # per-step calls marshalled in C++ when the extension is built and this engine drives the HIP library it is linked to
+        self._fast = _load_torch_ext() if (lib is None and not host_memory) else None
 
     # ------------------------------------------------------------------ helpers
     def _check(self, rc):
@@ -132,6 +152,12 @@ class Engine:
         """Returns (enhanced, workspace).  Keep `workspace` alive until backward has been enqueued."""
         if noisy.dim() != 3 or noisy.shape[1] != 1:
             raise WunetError(f"input must be [batch, 1, samples], got {tuple(noisy.shape)}")
+        if self._fast is not None:
+            with self._using(n_layers, ci, noisy.shape[0], noisy.shape[2], noisy.device) as h:
+                try:
+                    return self._fast.forward(h.value, noisy, params, running, nbt, bool(training), bool(with_backward))
+                except RuntimeError as e:
+                    raise WunetError(str(e).split("\n")[0]) from None
         self._require(noisy, "input")
         self._require_all(params, "param", noisy.device)
         self._require_all(running, "buffer", noisy.device)
@@ -153,6 +179,13 @@ class Engine:
         self._require(grad_enhanced, "grad_output")
         nl = 2 * n_layers + 1
         lb, le = layer_range if layer_range is not None else (0, nl)
+        if self._fast is not None and isinstance(grads, FlatGrads):
+            with self._using(n_layers, ci, B, T, noisy.device) as h:
+                try:
+                    self._fast.backward_range(h.value, noisy, params, enhanced, grad_enhanced, ws, grads.flat, grads.offsets, lb, le, bool(join))
+                except RuntimeError as e:
+                    raise WunetError(str(e).split("\n")[0]) from None
+            return
         fn = self.lib.wunet_backward_range if join else self.lib.wunet_backward_range_async
         if isinstance(grads, FlatGrads):         # one flat buffer + element offsets: the pointers are arithmetic, no 102 views first
             base = grads.flat.data_ptr()
@@ -203,6 +236,13 @@ class Engine:
 def _adam_step(self, params, grads, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, grad_scale=1.0, step_dev=None, hyper_dev=None):
     """One fused Adam step over a list of tensors.  step_dev (int64 device scalar) + hyper_dev (2 floats):
     the step count lives on the device and the call increments it (capturable in a hipGraph); otherwise `step` is the host's."""
+    if self._fast is not None:
+        try:
+            self._fast.adam_step(params, grads, exp_avg, exp_avg_sq, float(lr), float(beta1), float(beta2), float(eps), int(step),
+                                 float(grad_scale), step_dev, hyper_dev)
+        except RuntimeError as e:
+            raise WunetError(str(e).split("\n")[0]) from None
+        return
     for name, ts in (("param", params), ("grad", grads), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
         self._require_all(ts, "adam " + name, params[0].device)
     n = len(params)

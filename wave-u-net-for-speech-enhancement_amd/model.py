@@ -67,18 +67,17 @@ class _WaveUNetFn(torch.autograd.Function):
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=noisy.device)
         sync = owner.grad_sync
+        # the kernels only need addresses (flat buffer + offsets): enqueue first, cut the 102 views autograd wants while the GPU runs
+        offsets, off = [], 0
+        for n in sizes:
+            offsets.append(off)
+            off += n
+        fg = FlatGrads(flat, offsets)
         if sync is None:
-            # the kernels only need addresses (flat buffer + offsets): enqueue first, cut the 102 views autograd wants while the GPU runs
-            offsets, off = [], 0
-            for n in sizes:
-                offsets.append(off)
-                off += n
-            engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out.contiguous(),
-                            ctx.ws, FlatGrads(flat, offsets))
-            grads = [g.view(p.shape) for g, p in zip(flat.split(sizes), params)]
+            engine.backward(owner.n_layers, owner.channels_interval, noisy, params, out, grad_out.contiguous(), ctx.ws, fg)
         else:
-            grads = [g.view(p.shape) for g, p in zip(flat.split(sizes), params)]
-            sync.run(engine, owner, noisy, params, out, grad_out.contiguous(), ctx.ws, grads, flat)
+            sync.run(engine, owner, noisy, params, out, grad_out.contiguous(), ctx.ws, fg, flat)
+        grads = [g.view(p.shape) for g, p in zip(flat.split(sizes), params)]
         owner.last_flat_grad = flat
         ctx.ws = None
         return (None, None, None, *grads)
