@@ -54,3 +54,18 @@ def test_no_cpu_fallback(pkg):
         m(torch.zeros(1, 1, 64))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pkg.mse_loss()(torch.zeros(1, 1, 64), torch.zeros(1, 1, 64))
+
+
+def test_torch_extension_is_optional_and_exposes_the_three_calls():
+    """torch_ext/wunet_torch.cpp (built by __graft_entry__.build()): when it is there it loads without a GPU and exposes the three
+    per-step calls; the engine of an injected library (the emulator tests) never uses it."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    ext = eng_mod._load_torch_ext()
+    path = os.path.join(ROOT, PKG_NAME, "torch_ext", "_wunet_torch.so")
+    assert (ext is not None) == (os.path.exists(path) and not os.environ.get("WUNET_LIB_PATH") and not os.environ.get("WUNET_NO_TORCH_EXT"))
+    if ext is not None:
+        for name in ("forward", "backward_range", "adam_step"):
+            assert callable(getattr(ext, name))
+        # a CPU tensor is refused by the extension with the product path's message, before anything is enqueued
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            ext.adam_step([torch.zeros(3)], [torch.zeros(3)], [torch.zeros(3)], [torch.zeros(3)], 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None, None)
