@@ -270,9 +270,11 @@ def main():
                          "the 1e-4 fp32 parity bar)")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the training step as ONE captured hipGraph (torch.cuda.CUDAGraph over forward + loss + backward + "
-                         "fused Adam with its device-side step counter; SURVEY.md section 8 f2).  auto = off: measured on MI355X / "
-                         "ROCm 7.0 the replay of the ~230-node graph costs the host 0.8 ms instead of 2.2 but the GPU 10 %% more "
-                         "(5.84 vs 5.32 ms per step, profiles/r3_bench_graph.json), so the headline stays eager")
+                         "fused Adam with its device-side step counter; SURVEY.md section 8 f2).  auto = on for one GPU with the fused "
+                         "Adam: since the backward enqueues each layer's data gradient ahead of its side-stream weight gradient the "
+                         "replay is as fast as the eager step (5.25 vs 5.26 ms back to back, profiles/r4_graph_vs_eager.txt) and a loop "
+                         "that synchronises every step no longer pays the host's launch jitter (median 5.27 vs 5.5 ms); a failed "
+                         "capture falls back to eager launches (reported in config.step_launch)")
     ap.add_argument("--native-rccl", action="store_true",
                     help="the gradient all-reduce through the library's own RCCL entry (include/wunet_hip.h wunet_comm_*: enqueued on the "
                          "backward's streams, capturable with --graph on) instead of torch.distributed's process group; at --gpus 1 the "
@@ -342,7 +344,9 @@ def main():
         opt.step()
         return loss
 
-    use_graph = args.mode == "train" and args.graph == "on" and (world == 1 or args.native_rccl)
+    fused_adam = not args.torch_adam
+    use_graph = args.mode == "train" and fused_adam and (
+        (args.graph == "on" and (world == 1 or args.native_rccl)) or (args.graph == "auto" and world == 1))
     eager_step = step
     if use_graph:
         opt.device_step = True                   # the step counter and bias corrections live on the device: replayable
@@ -350,22 +354,30 @@ def main():
         step()
     if use_graph:
         # the same work as `step`, captured once: every kernel of forward, loss, backward (both streams) and the Adam step
-        torch.cuda.synchronize()
-        opt.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out_g = model(noisy)
-            loss_g = crit(clean, out_g)
-            loss_g.backward()
-            opt.step()
-        opt.advance_host_step(-1)                # capture does not execute
+        try:
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out_g = model(noisy)
+                loss_g = crit(clean, out_g)
+                loss_g.backward()
+                opt.step()
+            opt.advance_host_step(-1)                # capture does not execute
 
-        def step():
-            graph.replay()
-            opt.advance_host_step(1)
-            return loss_g
-        for _ in range(2):
-            step()
+            def step():
+                graph.replay()
+                opt.advance_host_step(1)
+                return loss_g
+            for _ in range(2):
+                step()
+        except Exception as e:                       # noqa: BLE001 - `auto` must never cost the bench line: eager launches instead
+            if args.graph == "on":
+                raise
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            use_graph = False
+            step = eager_step
+            torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()

@@ -747,6 +747,56 @@ def test_trainer_on_gpu_equals_the_written_out_loop(pkg, dev, tmp_path, graph):
     assert np.allclose(tr.epoch_losses, losses, rtol=1e-5)
 
 
+def test_trainer_graph_is_the_default_and_gives_way_to_a_per_step_lr_schedule(pkg, dev, tmp_path):
+    """One GPU + FusedAdam: the captured step graph is the Trainer's default ("graph" absent from the config).  lr / betas / eps are
+    kernel arguments of the captured Adam step, so a changed value forces a new capture: a schedule that changes the lr every step
+    must not turn every step into capture + instantiate + replay - after MAX_RECAPTURES such changes in a row the Trainer warns and
+    goes back to eager launches, and the parameters still equal the written-out loop with the same schedule bit for bit."""
+    trainer_mod = importlib.import_module(PKG_NAME + ".trainer")
+    dataset_mod = importlib.import_module(PKG_NAME + ".dataset")
+    optim_mod = importlib.import_module(PKG_NAME + ".optim")
+    n, ci, sl = 4, 8, 1024
+    ds = dataset_mod.Dataset(n_items=48, sample_length=sl, seed=3)
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
+
+    def make():
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in plan.golden_state(n, ci, 0).items()})
+        return m.to(dev), pkg.mse_loss()
+
+    cfg = {"root_dir": str(tmp_path), "experiment_name": "d", "trainer": {"epochs": 1, "save_checkpoint_interval": 0}}
+    m1, crit1 = make()
+    opt1 = optim_mod.FusedAdam(m1.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    tr = trainer_mod.Trainer(cfg, False, m1, crit1, opt1, loader, None)
+    assert tr.use_graph                                   # the default
+    lrs = [1e-3 * (0.97 ** k) for k in range(len(loader))]
+    steps = {"k": 0}
+    inner = tr._step
+
+    def scheduled(mixture, clean):                         # a per-step schedule, as an LR scheduler's step() would apply it
+        for g in opt1.param_groups:
+            g["lr"] = lrs[steps["k"]]
+        steps["k"] += 1
+        return inner(mixture, clean)
+
+    tr._step = scheduled
+    with pytest.warns(RuntimeWarning, match="falling back to eager"):
+        tr.train()
+    assert not tr.use_graph and steps["k"] == len(loader)
+    m2, crit2 = make()
+    opt2 = optim_mod.FusedAdam(m2.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    m2.train()
+    for k, (mix, cl, _) in enumerate(loader):
+        for g in opt2.param_groups:
+            g["lr"] = lrs[k]
+        opt2.zero_grad()
+        crit2(cl.to(dev), m2(mix.to(dev))).backward()
+        opt2.step()
+    torch.cuda.synchronize()
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
 def test_shard_loader_gathers_on_the_gpu(dev, tmp_path):
     """waveform_dataset.ShardLoader with device=cuda - the shard is uploaded once (piecewise from the
     memory map), every batch is ONE launch of crop_windows_kernel behind wunet_crop_windows.  Checked against an independent

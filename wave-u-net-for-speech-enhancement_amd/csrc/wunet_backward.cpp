@@ -173,9 +173,16 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         }
         // ---- weight gradient on the side stream: GEMM over positions on the materialised operands, split-K partials
         //      + deterministic reduce
+        // The fork EVENT is recorded here, right behind g_z; the side stream's launches are issued after the data gradient's (below), so
+        // that the kernel of the critical chain is enqueued - and, in a captured graph, created - FIRST: its persistent blocks take the
+        // CUs and the weight gradient fills in behind it and beside the next layer's memory-bound passes.  Eager launches got that order
+        // anyway (the event wait costs the side stream ~6 us); a captured graph released both kernels at once, the weight gradient
+        // won the race (data gradient 204 us instead of 110) and the replay was 10 % slower than the eager step (5.93 -> 5.25 ms with
+        // this order, eager 5.26: profiles/r4_graph_vs_eager.txt).
+        if (sd != st && hipEventRecord(side->ev_fork, st) != hipSuccess) return fail(WUNET_E_RUNTIME, "fork onto the weight-gradient stream failed");
         auto weight_gradient = [&]() -> int {
             if (sd != st) {
-                if (hipEventRecord(side->ev_fork, st) != hipSuccess || hipStreamWaitEvent(sd, side->ev_fork, 0) != hipSuccess)
+                if (hipStreamWaitEvent(sd, side->ev_fork, 0) != hipSuccess)
                     return fail(WUNET_E_RUNTIME, "fork onto the weight-gradient stream failed");
             }
             const float* xin = i == 0 ? noisy : ws + l.xin;
@@ -230,7 +237,6 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             }
             return 0;
         };
-        { const int rc = weight_gradient(); if (rc) return rc; }
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
         if (i > 0 && l.h3d) {
             // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
@@ -273,6 +279,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                 WUNET_CHECK_LAUNCH();
             }
         }
+        { const int rc = weight_gradient(); if (rc) return rc; }
     }
     // join: the caller's stream sees every weight gradient.  An un-joined range (wunet_backward_range_async) leaves them to
     // wunet_backward_join - except the range that ends the backward, which always joins: the next forward overwrites the

@@ -13,9 +13,10 @@ Differences from the reference loop, all on the f2 list:
     attaches the RCCL gradient all-reduce to the model instead of nn.DataParallel;
   * host->device copies are non_blocking from pinned memory (train.py:20 sets pin_memory but copies synchronously);
   * the loss is accumulated on the device and read back once per epoch (trainer.py:40 syncs every step);
-  * `"graph": true` in the trainer config (or WUNET_GRAPH=1): after a few eager steps the whole step - forward, loss, backward,
-    Adam (optim.FusedAdam with its device-side step counter) - is captured once in a hipGraph (torch.cuda.CUDAGraph) on static
-    input buffers and replayed: ~270 kernel launches become one graph launch per step;
+  * after a few eager steps the whole step - forward, loss, backward, Adam (optim.FusedAdam with its device-side step counter) - is
+    captured once in a hipGraph (torch.cuda.CUDAGraph) on static input buffers and replayed: ~230 kernel launches become one graph
+    launch per step (default on one GPU with FusedAdam; `"graph": false` in the trainer config or WUNET_GRAPH=0 keeps eager launches;
+    hyper-parameters that change every step - a per-step LR schedule - make it fall back to eager by itself);
   * checkpoints keep the reference's names and keys (base_trainer.py:83-124) so either side can resume; only rank 0 writes.
 """
 import os
@@ -28,6 +29,8 @@ from .optim import FusedAdam
 from .parallel import GradSync
 
 GRAPH_WARMUP_STEPS = 3
+MAX_RECAPTURES = 3           # hyper-parameter changes in a row (each closer than RECAPTURE_RESET replays to the last) before the graph is given up
+RECAPTURE_RESET = 50
 
 
 class Trainer:
@@ -63,7 +66,10 @@ class Trainer:
         self.validation_data_loader = validation_dataloader      # accepted for signature compatibility, unused
         self.epochs = tcfg["epochs"]
         self.save_checkpoint_interval = tcfg.get("save_checkpoint_interval", 0)
-        self.use_graph = bool(tcfg.get("graph", os.environ.get("WUNET_GRAPH", "0") not in ("", "0")))
+        # default ON where it can be used (one GPU, or the native RCCL entry; fused Adam): the replay is as fast as the eager
+        # launches back to back and a loop that synchronises every step (trainer/trainer.py:40 `loss.item()`) loses the host's launch
+        # jitter (profiles/r4_graph_vs_eager.txt).  "graph": false / WUNET_GRAPH=0 turns it off.
+        self.use_graph = bool(tcfg.get("graph", os.environ.get("WUNET_GRAPH", "1") not in ("", "0")))
         if self.use_graph and not (fused and self.device.type == "cuda" and (self.world == 1 or native)):
             # (torch.distributed's collectives stay outside a captured graph: their eager path overlaps them with the backward already;
             #  the native RCCL entry enqueues on the captured streams and is replayed with the step)
@@ -74,6 +80,8 @@ class Trainer:
         self._graph_sig = None
         self._static = None
         self._eager_steps = 0
+        self._recaptures = 0          # consecutive re-captures forced by a changed lr / betas / eps (a per-step LR schedule)
+        self._replays = 0
         self.start_epoch = 1
         self.best_score = float("-inf")
         root = Path(os.path.expanduser(config.get("root_dir", "."))).absolute() / config.get("experiment_name", "exp")
@@ -158,8 +166,18 @@ class Trainer:
             return self._eager_step(mixture, clean)
         if self._graph is not None and self.optimizer.hyper_signature() != self._graph_sig:
             # lr / betas / eps / grad_scale are kernel arguments of the captured Adam step: a scheduler, a manual decay or a
-            # load_state_dict with another lr would be ignored by the replay - capture again with the new values
+            # load_state_dict with another lr would be ignored by the replay - capture again with the new values.  A schedule that
+            # changes them EVERY step would turn each step into capture + instantiate + one replay (far slower than eager): after
+            # MAX_RECAPTURES changes with fewer than RECAPTURE_RESET replays in between, the graph is given up for eager launches.
             self._graph = None
+            self._recaptures = self._recaptures + 1 if self._replays < RECAPTURE_RESET else 1
+            self._replays = 0
+            if self._recaptures > MAX_RECAPTURES:
+                import warnings
+                warnings.warn("Trainer: the optimiser's hyper-parameters change every few steps (a per-step LR schedule?); the captured "
+                              "step graph would be rebuilt each time - falling back to eager launches", RuntimeWarning)
+                self.use_graph = False
+                return self._eager_step(mixture, clean)
         if self._graph is None:
             if self._eager_steps < GRAPH_WARMUP_STEPS:
                 self._eager_steps += 1
@@ -171,6 +189,7 @@ class Trainer:
         self._static[0].copy_(mixture, non_blocking=True)
         self._static[1].copy_(clean, non_blocking=True)
         self._graph.replay()
+        self._replays += 1
         self.optimizer.advance_host_step(1)
         return self._static_loss
 
