@@ -36,6 +36,12 @@ def test_native_library_is_the_hip_one(engine):
     lib_mod = importlib.import_module(PKG_NAME + "._lib")
     assert engine.lib is lib_mod.load_hip() and not engine.host_memory
     assert "libwunet_hip.so" in open("/proc/self/maps").read()
+    # ... and the per-step calls go through the PyTorch C++ extension build() makes (torch_ext/wunet_torch.cpp, the form north_star
+    # names), not through its ctypes stand-in: a broken extension build must not pass as a 0.2 ms slower host path
+    import os
+    if not os.environ.get("WUNET_NO_TORCH_EXT") and not os.environ.get("WUNET_LIB_PATH"):
+        assert engine._fast is not None, "torch_ext/_wunet_torch.so is missing or was built against another torch: run __graft_entry__.build()"
+        assert "_wunet_torch.so" in open("/proc/self/maps").read()
 
 
 def test_cpu_tensor_is_rejected(pkg):

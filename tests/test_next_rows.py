@@ -216,8 +216,40 @@ def test_fused_adam_shared_step_counter_is_invisible(emu_engine):
     fd = optim_mod.FusedAdam(pa, lr=1e-2, device_step=True)
     fd._engine_override = emu_engine
     fd.load_state_dict(fa.state_dict())
+    before = [(int(fd.state[p]["step"]), fd.state[p]["step"], fd.state[p]["exp_avg"].clone(), p.detach().clone()) for p in pa]
     with pytest.raises(RuntimeError, match="share the step count"):
         fd.step()
+    # ... and refuses BEFORE it touches anything: a caller that catches the error finds counters (the same objects), moments and
+    # parameters as they were
+    for p, (n0, obj, m0, p0) in zip(pa, before):
+        assert int(fd.state[p]["step"]) == n0 and fd.state[p]["step"] is obj
+        assert torch.equal(fd.state[p]["exp_avg"], m0) and torch.equal(p.detach(), p0)
+
+
+def test_bump_versions_on_a_torch_that_takes_one_tensor(monkeypatch):
+    """torch 2.1 - 2.4: torch.autograd.graph.increment_version takes ONE tensor (a list raises TypeError); engine.bump_versions then
+    goes tensor by tensor instead of failing every training forward and optimiser step."""
+    engine_mod = importlib.import_module(PKG_NAME + ".engine")
+    real = torch.autograd.graph.increment_version
+    calls = []
+
+    def one_tensor_only(t):
+        if not isinstance(t, torch.Tensor):
+            raise TypeError("increment_version(): argument 'tensor' must be Tensor, not list")
+        calls.append(t)
+        real(t)
+
+    monkeypatch.setattr(torch.autograd.graph, "increment_version", one_tensor_only)
+    a, b = torch.zeros(3), torch.zeros(2)
+    va, vb = a._version, b._version
+    engine_mod.bump_versions([a, b])
+    assert a._version == va + 1 and b._version == vb + 1 and len(calls) == 2
+
+
+def test_native_comm_wants_rank_with_world():
+    par = importlib.import_module(PKG_NAME + ".parallel")
+    with pytest.raises(ValueError, match="rank"):
+        par.NativeComm(world=2)
 
 
 def test_batched_validation_names_the_offending_tensor(emu_engine):

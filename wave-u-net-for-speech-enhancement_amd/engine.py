@@ -19,10 +19,15 @@ class WunetError(RuntimeError):
 
 def bump_versions(tensors):
     """Tell autograd's version counters that a kernel wrote these tensors through raw pointers (what every in-place torch op does
-    by itself).  torch >= 2.1 has the call; older ones are left as they were."""
+    by itself).  torch >= 2.1 has the call (a list where it is accepted, else tensor by tensor); older ones are left as they were."""
     inc = getattr(torch.autograd.graph, "increment_version", None)
-    if inc is not None:
-        inc(tensors)
+    if inc is None:
+        return
+    try:
+        inc(tensors)                     # (recent torch takes the whole list)
+    except TypeError:                    # torch 2.1 - 2.4: one tensor per call
+        for t in tensors:
+            inc(t)
 
 
 class FlatGrads:
@@ -38,7 +43,13 @@ def _load_torch_ext():
     if os.environ.get("WUNET_LIB_PATH") or os.environ.get("WUNET_NO_TORCH_EXT"):
         return None
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "torch_ext", "_wunet_torch.so")
+    stamp = path + ".torch"              # the torch version the extension was built against (__graft_entry__._build_torch_ext)
     if not os.path.exists(path):
+        return None
+    try:
+        if open(stamp).read().strip() != torch.__version__:
+            return None                  # built against another torch: its ABI is not this one's - the ctypes path instead
+    except OSError:
         return None
     try:
         import importlib.util

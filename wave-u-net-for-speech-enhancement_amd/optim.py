@@ -117,6 +117,11 @@ class FusedAdam(torch.optim.Optimizer):
                 by = {}
                 for k, t in enumerate(steps):
                     by.setdefault(float(t.item()), []).append(k)
+                if self.device_step and len(by) != 1:
+                    # (checked BEFORE any counter is rewritten: a caller that catches this finds host counters, device counter and
+                    # moments as they were)
+                    raise RuntimeError("FusedAdam(device_step=True): the parameters of one group must share the step count "
+                                       "(the group has ONE counter on the device)")
                 launches = []
                 for v, idx in by.items():
                     sv = torch.tensor(v + 1.0, dtype=torch.float32)

@@ -27,6 +27,8 @@ class NativeComm:
         if world is None:
             world = dist.get_world_size(group) if dist.is_initialized() else 1
             rank = dist.get_rank(group) if dist.is_initialized() else 0
+        elif rank is None:
+            raise ValueError("NativeComm: pass `rank` together with `world`")
         self.world, self.rank = world, rank
         buf = (ctypes.c_ubyte * 128)()
         if comm_id is None:
@@ -37,7 +39,9 @@ class NativeComm:
                     self.engine._check(rc)
                 box[0] = bytes(buf)
             if world > 1:
-                dist.broadcast_object_list(box, src=0, group=group)
+                # (src is a GLOBAL rank: the group's rank 0 drew the id)
+                src = dist.get_global_rank(group, 0) if group is not None else 0
+                dist.broadcast_object_list(box, src=src, group=group)
             comm_id = box[0]
         buf = (ctypes.c_ubyte * 128)(*comm_id)
         self.handle = ctypes.c_void_p()

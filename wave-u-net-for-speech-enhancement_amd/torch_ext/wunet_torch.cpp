@@ -123,7 +123,9 @@ void adam_step(const std::vector<at::Tensor>& params, const std::vector<at::Tens
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
-    m.def("forward", &forward);
-    m.def("backward_range", &backward_range);
-    m.def("adam_step", &adam_step);
+    // (the GIL is released for the whole call: the functions only read tensor metadata / pointers and allocate through ATen, both
+    // thread-safe - stock nn.DataParallel enqueues its replicas from one thread each, trainer/base_trainer.py:26-27)
+    m.def("forward", &forward, py::call_guard<py::gil_scoped_release>());
+    m.def("backward_range", &backward_range, py::call_guard<py::gil_scoped_release>());
+    m.def("adam_step", &adam_step, py::call_guard<py::gil_scoped_release>());
 }
