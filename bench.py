@@ -438,6 +438,12 @@ def main():
             with torch.no_grad():
                 model(noisy)
         extras["eval_forward"] = timed(fwd, 10, 20, args.batch, "eval-mode forward only (BASELINE configs[1], enhancement.py path), default GEMM arithmetic")
+        if not args.no_roofline:
+            # BASELINE configs[1] carries its own roofline: the dominant GEMM kernel of the eval forward (HIP events of the same calls)
+            # and the PMC traffic of its own passes (tools/measure_round.sh: `bench.py --mode forward` under --pmc)
+            extras["eval_forward"]["roofline"] = roofline_of(kernel_rows(engine_mod.default_engine().lib, fwd, 3), 3, load_pmc_traffic("eval_forward"),
+                                                             args.batch * fwd_bytes)
+            extras["eval_forward"]["whole_forward_tflops"] = extras["eval_forward"]["frames_per_s"] * fwd_flop / 1e12
         model.train()
         torch.manual_seed(0)
         m32 = pkg.Model(n_layers=args.layers, channels_interval=CI).to(device).train()

@@ -67,8 +67,14 @@ size_t wunet_workspace_bytes(const wunet_ctx* ctx, int with_backward);
 /* Replaces Model.forward (model/unet_basic.py:77-100).
  * training != 0: BatchNorm uses batch statistics and updates running_mean/var (momentum 0.1,
  * unbiased variance) and num_batches_tracked in place; otherwise running statistics are used.
- * save_for_backward != 0 (needs a with_backward=1 workspace): additionally keeps what wunet_backward
- * needs - the raw conv outputs, BN statistics and each conv's activated input. */
+ * save_for_backward: bit 0 (WUNET_FWD_SAVE, needs a with_backward=1 workspace): additionally keeps what wunet_backward
+ * needs - the raw conv outputs, BN statistics and each conv's activated input.
+ * Bit 1 (WUNET_FWD_PACKS_VALID, eval mode only): the caller asserts that `workspace` is the one the previous eval-mode wunet_forward of
+ * this ctx ran on and that no conv weight has changed since - the weight packs and weight scales it holds are reused and the three
+ * pack launches are skipped (enhancement.py:57-69 runs the same weights over every chunk of every file; engine.Engine keys this on the
+ * parameters' addresses and autograd version counters). */
+#define WUNET_FWD_SAVE 1
+#define WUNET_FWD_PACKS_VALID 2
 int wunet_forward(wunet_ctx* ctx, const float* noisy, const float* const* params,
                   float* const* running, long long* const* num_batches_tracked, int training,
                   int save_for_backward, void* workspace, float* enhanced, void* stream);

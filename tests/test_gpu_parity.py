@@ -185,7 +185,8 @@ def test_layer_activations_vs_oracle(pkg, engine, dev):
 
 def test_full_size_properties(pkg, dev):
     """BASELINE.json configs[1]/[2] size (12-level, batch 64 x 16384).
-    (a) eval mode: frames are independent -> the batch-64 output equals the outputs of 8-frame slices;
+    (a) eval mode: frames are independent -> the batch-64 output equals the outputs of 8-frame slices, and it equals the reference's
+        eval-mode forward on the CPU (BASELINE configs[1]) within 1e-4;
     (b) train mode: forward / loss / gradients against the reference's own ATen CPU path
         (oracle/torch_port.py, bit-identical to the imported reference, see tests/golden/make_golden.py)."""
     n, ci, B, T = 12, 24, 64, 16384
@@ -197,6 +198,13 @@ def test_full_size_properties(pkg, dev):
     # (to rounding: the power-of-two scale of a split operand derives from the measured activation maximum of the batch at hand,
     # so a 64-frame and an 8-frame forward may round the same operand at different binades)
     assert (sliced - out_eval).abs().max().item() <= 5e-6
+    # ... and against the reference's own eval-mode path at this size (enhancement.py:43,65-66: model.eval(), running statistics), ATen on
+    # the CPU: the 1e-4 bar of north_star
+    with torch.no_grad():
+        ref_eval = torch_port.forward(torch_port.state_to_torch(plan.golden_state(n, ci, 0), requires_grad=False), torch.from_numpy(noisy), n, ci, False)
+    e_eval = (out_eval.detach().cpu() - ref_eval).abs().max().item()
+    print(f"full size: eval-mode output, batch 64, max |diff| to the reference {e_eval:.2e}")
+    assert e_eval < TOL
 
     m, out, lv = _run_model(pkg, dev, n, ci, noisy, clean, "smooth_l1")
     tsd = torch_port.state_to_torch(plan.golden_state(n, ci, 0), requires_grad=True)
@@ -751,6 +759,55 @@ def test_trainer_on_gpu_equals_the_written_out_loop(pkg, dev, tmp_path, graph):
         assert int(s1["step"]) == int(s2["step"]) == 8
         assert torch.equal(s1["exp_avg"], s2["exp_avg"]) and torch.equal(s1["exp_avg_sq"], s2["exp_avg_sq"])
     assert np.allclose(tr.epoch_losses, losses, rtol=1e-5)
+
+
+def test_eval_forward_reuses_its_weight_packs_until_a_weight_changes(pkg, dev):
+    """Eval mode (enhancement.py:57-69 runs one set of weights over every chunk): engine.Engine hands the workspace of the previous eval
+    forward back to the library with WUNET_FWD_PACKS_VALID while no parameter's address or autograd version has moved - the three
+    pack launches are skipped.  The results must not know: a repeated forward is bit-identical, an in-place weight update (what an
+    optimiser step or load_state_dict does) is seen at once, and a `.data` edit behind autograd's back is seen after drop_eval_cache()."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    n, ci, B, T = 12, 24, 4, 16384
+    sd = plan.golden_state(n, ci, 0)
+    noisy, _ = plan.golden_batch(B, T, 5)
+    x = _t(noisy, dev)
+
+    def fresh(scale_layer=None):
+        m = pkg.Model(n_layers=n, channels_interval=ci)
+        m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+        m._engine_override = eng_mod.Engine()                 # (its own engine: nothing cached)
+        m.to(dev).eval()
+        if scale_layer is not None:
+            with torch.no_grad():
+                m.encoder[scale_layer].main[0].weight.mul_(1.25)
+        with torch.no_grad():
+            return m, m(x)
+
+    m, o1 = fresh()
+    eng = m._engine_override
+    with torch.no_grad():
+        o2 = m(x)                                             # packs reused
+        o3 = m(x)
+    assert len(eng._eval_ws) == 1
+    assert torch.equal(o1, o2) and torch.equal(o1, o3)
+    with torch.no_grad():
+        m.encoder[3].main[0].weight.mul_(1.25)                # in place: the version counter moves, the packs are rebuilt
+        o4 = m(x)
+    _, ref4 = fresh(scale_layer=3)
+    assert torch.equal(o4, ref4) and not torch.equal(o4, o1)
+    m.encoder[5].main[0].weight.data.mul_(1.25)               # behind autograd's back: not seen ...
+    with torch.no_grad():
+        assert torch.equal(m(x), o4)
+        eng.drop_eval_cache()                                 # ... until the caller says so
+        o5 = m(x)
+    assert not torch.equal(o5, o4)
+    # a training forward in between neither uses nor disturbs the cached eval workspace
+    m.train()
+    m(x).sum().backward()
+    m.eval()
+    with torch.no_grad():
+        o6 = m(x)
+    assert torch.isfinite(o6).all()
 
 
 def test_trainer_graph_is_the_default_and_gives_way_to_a_per_step_lr_schedule(pkg, dev, tmp_path):

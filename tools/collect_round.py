@@ -64,9 +64,9 @@ head = section("train")
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) of bench.py --steps 2 --warmup 1; HBM bytes per "
                 "launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction); whole_step_bytes = sum over ALL kernels of one step, "
                 "torch's own (optimizer state init, fills) included.  Top level: the headline workload (12 levels, batch 64, split GEMMs); "
-                "sections: the same passes of bench.py --gemm fp32 and of --gemm bf16 --layers 16 --frame 65536 --batch 32 (configs[4])",
+                "sections: the same passes of bench.py --gemm fp32, of --gemm bf16 --layers 16 --frame 65536 --batch 32 (configs[4]) and of --mode forward (configs[1])",
        "tag": tag, "source_hash": bench.source_hash(), "whole_step_bytes": head["whole_step_bytes"], "kernels": head["kernels"], "sections": {}}
-for name in ("gemm_fp32", "deep16_bf16"):
+for name in ("gemm_fp32", "deep16_bf16", "eval_forward"):
     if os.path.exists(os.path.join(F, f"pmc_raw_{name}.json")):
         out["sections"][name] = section(name)
 json.dump(out, open(os.path.join(P, "pmc_traffic.json"), "w"), indent=1)

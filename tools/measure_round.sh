@@ -12,7 +12,7 @@ pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 s
     local name=$1; shift
     for ctr in FETCH_SIZE WRITE_SIZE; do
         WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $O/pmc_${name}_$ctr -o p -- \
-            python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras "$@" > /dev/null 2>&1
+            python $R/bench.py --steps 2 --warmup 1 --graph off --no-cpu-baseline --no-roofline --no-extras "$@" > /dev/null 2>&1
     done
     python - <<PY
 import collections, csv, glob, json
@@ -34,15 +34,16 @@ PY
 pmc_pass train
 pmc_pass gemm_fp32 --gemm fp32
 pmc_pass deep16_bf16 --gemm bf16 --layers 16 --frame 65536 --batch 32
+pmc_pass eval_forward --mode forward
 cd $R; python tools/collect_round.py $TAG --pmc-only
 # SQ / GRBM counters of the serial step (one stream: kernels do not overlap, so counters and durations belong to one kernel)
 cd /tmp
 WUNET_NO_SIDE_STREAM=1 WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace \
     --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F16 \
-    --output-format csv -d $O/pmc_sq -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+    --output-format csv -d $O/pmc_sq -o s -- python $R/bench.py --steps 2 --warmup 1 --graph off --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
 WUNET_NO_SIDE_STREAM=1 WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace \
     --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU \
-    --output-format csv -d $O/pmc_grbm -o g -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
+    --output-format csv -d $O/pmc_grbm -o g -- python $R/bench.py --steps 2 --warmup 1 --graph off --no-cpu-baseline --no-roofline --no-extras > /dev/null 2>&1
 python $R/tools/pmc_sq.py $O/pmc_sq $O/pmc_grbm > $O/pmc_sq.txt 2> $O/pmc_sq.err
 rm -rf $O/pmc_sq $O/pmc_grbm
 cd $R

@@ -14,6 +14,9 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
     if (!c || !noisy || !params || !running || !nbt || !workspace || !enhanced) return fail(WUNET_E_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
     float* ws = (float*)workspace;
+    // (eval mode, the caller's workspace still holds this ctx's packs of these weights: nothing to pack)
+    const bool packs_valid = !training && (save_for_backward & WUNET_FWD_PACKS_VALID) != 0;
+    save_for_backward &= WUNET_FWD_SAVE;
     // The skip half of each decoder input only depends on an encoder level and could run on the side stream during
     // the encoder phase; measured on MI355X that is SLOWER (forward 4.24 vs 3.99 ms: the elementwise kernel steals
     // L2/HBM bandwidth and CU slots from the encoder GEMMs), so it stays on the caller's stream.
@@ -58,8 +61,14 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         }
         return 0;
     };
-    if (!fside) { const int rc = pack_fp32(); if (rc) return rc; }
-    if (c->h3) {
+    if (!fside && !packs_valid) { const int rc = pack_fp32(); if (rc) return rc; }
+    if (c->h3 && packs_valid) {
+        ScaleTable T{};
+        for (int i = 0; i < c->NL; ++i) T.d[i].zp0 = c->ly[i].h3f ? ws + c->ly[i].xzp : nullptr;
+        T.slots = ws + c->fslot_off;
+        WUNET_LAUNCH(h3_slots_clear_kernel, dim3(1), dim3(WUNET_THREADS), 0, st, T, c->NL);
+        WUNET_CHECK_LAUNCH();
+    } else if (c->h3) {
         // power-of-two scales of the split operands (wunet_h3_elem.h): partial max |W| of every layer with a split pack, and
         // the activation bounds the x scales derive from (training: from gamma / beta; eval: cleared here, measured per layer)
         {

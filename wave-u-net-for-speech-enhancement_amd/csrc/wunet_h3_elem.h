@@ -62,6 +62,18 @@ static __global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTa
     }
 }
 
+// eval mode with reused weight packs (WUNET_FWD_PACKS_VALID): what h3_scales_kernel does beside the weight maxima - the activation
+// bounds cleared (the conv epilogues / act_max_kernel fold this call's maxima into them), the DMA zero pads rewritten.  One block.
+static __global__ __launch_bounds__(WUNET_THREADS) void h3_slots_clear_kernel(ScaleTable T, int nl)
+{
+    for (int i = threadIdx.x; i < nl * 5; i += WUNET_THREADS) {
+        const int layer = i / 5, k = i - layer * 5;
+        const ScaleDesc& d = T.d[layer];
+        if (k == 4) T.slots[layer * WUNET_SLOT_FLOATS + 4] = 0.0f;
+        else if (d.zp0) d.zp0[k] = 0.0f;
+    }
+}
+
 // eval mode: xb = max |a_c z + s_c| over the layer (>= |LeakyReLU(.)|), block maxima combined with atomicMax on the bit
 // pattern of the non-negative float (exact and order independent: deterministic)
 static __global__ __launch_bounds__(WUNET_THREADS) void act_max_kernel(const float* z, const float* a, const float* s, int C, int logL,

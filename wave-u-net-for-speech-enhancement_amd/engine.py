@@ -78,6 +78,7 @@ class Engine:
         # least-recently-used ones are destroyed beyond MAX_CONTEXTS (variable-length inference would otherwise leak one per shape)
         self._ctx = collections.OrderedDict()
         self._lock = threading.Lock()
+        self._eval_ws = collections.OrderedDict()     # (shape, device, stream) -> (workspace of the last eval forward, parameter signature)
         # per-step calls marshalled in C++ when the extension is built and this engine drives the HIP library it is linked to
         self._fast = _load_torch_ext() if (lib is None and not host_memory) else None
 
@@ -163,12 +164,27 @@ class Engine:
         """Returns (enhanced, workspace).  Keep `workspace` alive until backward has been enqueued."""
         if noisy.dim() != 3 or noisy.shape[1] != 1:
             raise WunetError(f"input must be [batch, 1, samples], got {tuple(noisy.shape)}")
+        # eval mode (enhancement.py:57-69: the same weights over every chunk of every file): the workspace of the previous eval forward
+        # on this (shape, device, stream) is used again, and while no parameter has changed - addresses and autograd version counters,
+        # which every in-place torch op, load_state_dict and FusedAdam.step move - the weight packs in it are not rebuilt
+        cache = sig = None
+        if not training and not with_backward and not self.host_memory and not os.environ.get("WUNET_NO_EVAL_CACHE"):      # (switch: A/B)
+            key = (n_layers, ci, noisy.shape[0], noisy.shape[2], str(noisy.device), torch.cuda.current_stream(noisy.device).cuda_stream)
+            sig = tuple((p.data_ptr(), p._version) for p in params)
+            with self._lock:
+                cache = self._eval_ws.pop(key, None)             # (popped: a second thread on the same key takes a fresh workspace)
+            if cache is not None and cache[1] != sig:
+                cache = (cache[0], None)
         if self._fast is not None:
             with self._using(n_layers, ci, noisy.shape[0], noisy.shape[2], noisy.device) as h:
                 try:
-                    return self._fast.forward(h.value, noisy, params, running, nbt, bool(training), bool(with_backward))
+                    out, ws = self._fast.forward(h.value, noisy, params, running, nbt, bool(training), bool(with_backward),
+                                                 cache[0] if cache else None, bool(cache and cache[1] is not None))
                 except RuntimeError as e:
                     raise WunetError(str(e).split("\n")[0]) from None
+            if sig is not None:
+                self._remember_eval_ws(key, ws, sig)
+            return out, ws
         self._require(noisy, "input")
         self._require_all(params, "param", noisy.device)
         self._require_all(running, "buffer", noisy.device)
@@ -176,12 +192,30 @@ class Engine:
         B, _, T = noisy.shape
         with self._using(n_layers, ci, B, T, noisy.device) as h, self._device_guard(noisy.device):
             nbytes = self.lib.wunet_workspace_bytes(h, 1 if with_backward else 0)
-            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=noisy.device)
+            reuse = cache is not None and cache[0].numel() * 4 >= nbytes
+            ws = cache[0] if reuse else torch.empty(nbytes // 4, dtype=torch.float32, device=noisy.device)
             out = torch.empty_like(noisy)
+            flags = (1 if with_backward else 0) | (2 if reuse and cache[1] is not None else 0)          # WUNET_FWD_SAVE | WUNET_FWD_PACKS_VALID
             self._check(self.lib.wunet_forward(h, noisy.data_ptr(), self._ptrs(params), self._ptrs(running),
-                                               self._ptrs(nbt), 1 if training else 0, 1 if with_backward else 0, ws.data_ptr(),
+                                               self._ptrs(nbt), 1 if training else 0, flags, ws.data_ptr(),
                                                out.data_ptr(), self._stream(noisy.device)))
+        if sig is not None:
+            self._remember_eval_ws(key, ws, sig)
         return out, ws
+
+    MAX_EVAL_WORKSPACES = 4
+
+    def _remember_eval_ws(self, key, ws, sig):
+        with self._lock:
+            self._eval_ws[key] = (ws, sig)
+            while len(self._eval_ws) > self.MAX_EVAL_WORKSPACES:            # (variable-length inference: the oldest shapes go)
+                self._eval_ws.pop(next(iter(self._eval_ws)))
+
+    def drop_eval_cache(self):
+        """Forget the eval-mode workspaces (and with them the cached weight packs): for a caller that changed weights behind autograd's
+        back (`p.data[...] = ...` does not move a version counter)."""
+        with self._lock:
+            self._eval_ws.clear()
 
     def backward(self, n_layers, ci, noisy, params, enhanced, grad_enhanced, ws, grads, layer_range=None, join=True):
         """join=False: the caller's stream does not wait for the range's weight gradients (side stream); make a stream see them

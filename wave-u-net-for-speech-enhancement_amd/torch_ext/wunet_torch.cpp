@@ -54,7 +54,7 @@ void* current_stream(const c10::Device& dev) { return (void*)c10::hip::getCurren
 
 std::tuple<at::Tensor, at::Tensor> forward(int64_t handle, const at::Tensor& noisy, const std::vector<at::Tensor>& params,
                                            const std::vector<at::Tensor>& running, const std::vector<at::Tensor>& nbt, bool training,
-                                           bool with_backward)
+                                           bool with_backward, const c10::optional<at::Tensor>& ws_reuse, bool packs_valid)
 {
     wunet_ctx* h = reinterpret_cast<wunet_ctx*>(handle);
     const c10::Device dev = noisy.device();
@@ -64,12 +64,16 @@ std::tuple<at::Tensor, at::Tensor> forward(int64_t handle, const at::Tensor& noi
     require_all(nbt, "buffer", dev, at::kLong);
     c10::DeviceGuard guard(dev);
     const size_t nbytes = wunet_workspace_bytes(h, with_backward ? 1 : 0);
-    at::Tensor ws = at::empty({(int64_t)(nbytes / 4)}, noisy.options());
+    // (eval mode: engine.Engine hands back the workspace of its previous eval forward on this ctx, packs_valid when the weights are unchanged)
+    at::Tensor ws = (ws_reuse && (size_t)ws_reuse->numel() * 4 >= nbytes && ws_reuse->device() == dev) ? *ws_reuse
+                                                                                                    : at::empty({(int64_t)(nbytes / 4)}, noisy.options());
+    if (!(ws_reuse && ws.is_same(*ws_reuse))) packs_valid = false;
     at::Tensor out = at::empty_like(noisy);
     auto pp = pointers<const float>(params);
     auto rp = pointers<float>(running);
     auto np = pointers<long long>(nbt);
-    const int rc = wunet_forward(h, noisy.data_ptr<float>(), pp.data(), rp.data(), np.data(), training ? 1 : 0, with_backward ? 1 : 0,
+    const int rc = wunet_forward(h, noisy.data_ptr<float>(), pp.data(), rp.data(), np.data(), training ? 1 : 0,
+                                 (with_backward ? WUNET_FWD_SAVE : 0) | (packs_valid && !training ? WUNET_FWD_PACKS_VALID : 0),
                                  ws.data_ptr(), out.data_ptr<float>(), current_stream(dev));
     if (rc) fail_rc(rc);
     return {out, ws};
@@ -125,7 +129,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     // (the GIL is released for the whole call: the functions only read tensor metadata / pointers and allocate through ATen, both
     // thread-safe - stock nn.DataParallel enqueues its replicas from one thread each, trainer/base_trainer.py:26-27)
-    m.def("forward", &forward, py::call_guard<py::gil_scoped_release>());
+    m.def("forward", &forward, py::arg("handle"), py::arg("noisy"), py::arg("params"), py::arg("running"), py::arg("nbt"), py::arg("training"),
+          py::arg("with_backward"), py::arg("ws_reuse") = py::none(), py::arg("packs_valid") = false, py::call_guard<py::gil_scoped_release>());
     m.def("backward_range", &backward_range, py::call_guard<py::gil_scoped_release>());
     m.def("adam_step", &adam_step, py::call_guard<py::gil_scoped_release>());
 }
