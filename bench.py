@@ -410,6 +410,25 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     frames_per_s = args.batch * world * args.steps / elapsed
 
+    # the gradient exchange of this job, per rank: what part of the bucketed all-reduces did not hide under the backward (device events
+    # around the join of a few extra steps), the buckets, the world size the transport reports
+    exchange = None
+    sync = getattr(model, "grad_sync", None)
+    if sync is not None and args.mode == "train":
+        sync.measure = True
+        for _ in range(5):
+            eager_step()
+        torch.cuda.synchronize()
+        sync.measure = False
+        ex = sync.exposed_ms()
+        mine = torch.tensor([sum(ex) / max(len(ex), 1)], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        exchange = sync.describe(model._wunet_params(), 2 * args.layers + 1)
+        exchange["allreduce_exposed_ms_per_rank"] = [round(float(t.item()), 4) for t in allr]
+        exchange["measured_over_steps"] = len(ex)
+
     roofline = None
     nprof = max(1, min(args.steps, 5))
     if rank != 0 and not args.no_roofline:
@@ -529,6 +548,7 @@ def main():
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": enqueue / args.steps * 1e3,
             "step_launch": "one hipGraph replay per step" if use_graph else "eager launches",
+            "gradient_exchange": exchange,
             "roofline": roofline, "cpu_baseline": cpu, "extras": extras,
         }
         result_out.write(json.dumps(result) + "\n")

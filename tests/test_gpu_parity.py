@@ -1138,3 +1138,55 @@ def test_grad_sync_world2_on_the_hardware(tmp_path):
     k = "encoder.1.main.0.weight"
     avg = sum(ref[k].astype(np.float64) for ref in refs) / world
     assert np.abs(whole[k] - avg).max() > 1e-3 * np.abs(avg).max()      # (one shard of the whole batch is a different number)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The library's own RCCL entry at world size 2: a one-GPU box cannot complete it (RCCL refuses two ranks on one device), but the path
+# of an N > 1 job up to and INTO ncclCommInitRank must run - id drawn on rank 0, carried to rank 1, wunet_comm_create on both - and end in
+# the library's error text instead of a hang or a crash.  (A box with >= 2 GPUs takes the other branch: the all-reduce itself.)
+def _native_world2_worker(rank, world, port, tmpdir):
+    import os
+    import sys
+    import torch.distributed as dist
+    from conftest import PKG_NAME as PKG, ROOT
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        parallel = importlib.import_module(PKG + ".parallel")
+        engine_mod = importlib.import_module(PKG + ".engine")
+        ndev = torch.cuda.device_count()
+        torch.cuda.set_device(rank % ndev)
+        msg = "ok"
+        try:
+            comm = parallel.NativeComm()
+            t = torch.full((1024,), float(rank + 1), device=f"cuda:{rank % ndev}")
+            comm.all_reduce_(t)
+            torch.cuda.synchronize()
+            msg = f"sum={t[0].item()} world={engine_mod.default_engine().lib.wunet_comm_world(comm.handle)}"
+            comm.close()
+        except engine_mod.WunetError as e:
+            msg = f"WunetError: {e}"
+        with open(os.path.join(tmpdir, f"rank{rank}.txt"), "w") as f:
+            f.write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(300)
+def test_native_rccl_world2_reaches_rccl(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_native_world2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    msgs = [open(str(tmp_path / f"rank{r}.txt")).read() for r in range(2)]
+    if torch.cuda.device_count() >= 2:
+        assert all(m.startswith("sum=3.0 world=2") for m in msgs), msgs       # 1 + 2 over the two ranks
+    else:
+        # both ranks came back from ncclCommInitRank with RCCL's own message through wunet_last_error
+        assert all("ncclCommInitRank failed" in m for m in msgs), msgs

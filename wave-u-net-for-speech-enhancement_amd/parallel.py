@@ -106,6 +106,10 @@ class GradSync:
         self.scale_in_optimizer = scale_in_optimizer
         self._ranges = {}
         self._launch_streams = {}
+        # measure=True: device events around the point where the backward's stream waits for the collectives - the part of the
+        # all-reduces that did NOT hide under the backward (bench.py --gpus N reports it per rank); read with exposed_ms()
+        self.measure = False
+        self._exposed = []
 
     def world_size(self):
         if self.comm is not None:
@@ -147,10 +151,12 @@ class GradSync:
             else:
                 work = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             pending.append((work, seg))
+        ev = self._mark(noisy) if (pending and on_gpu) else None
         for work, seg in pending:
             work.wait()                  # stream-level dependency on the RCCL stream, host does not block
             if not self.scale_in_optimizer:
                 seg.mul_(1.0 / world)
+        self._mark(noisy, ev)
 
     def _run_native(self, engine, owner, noisy, params, out, grad_out, ws, grads, flat, world):
         """The same schedule with the library's own RCCL entry: every bucket's all-reduce is enqueued on the launch stream C behind
@@ -176,4 +182,39 @@ class GradSync:
                 if not self.scale_in_optimizer:
                     seg.mul_(1.0 / world)
         if on_gpu:
+            ev = self._mark(noisy)
             main.wait_stream(launch)
+            self._mark(noisy, ev)
+
+    def _mark(self, noisy, first=None):
+        if not self.measure or not noisy.is_cuda:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream(noisy.device))
+        if first is not None:
+            self._exposed.append((first, e))
+        return e
+
+    def exposed_ms(self):
+        """Per measured backward: the time torch's stream spent between reaching the join and getting past it (device events; call after
+        a synchronize).  Clears the list."""
+        out = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return out
+
+    def describe(self, params, n_conv_layers):
+        """What a scaling record should say about the exchange: world size as the transport reports it, the transport, the buckets in
+        backward order (bytes)."""
+        rs = self.ranges_for(params, n_conv_layers)
+        if self.comm is not None:
+            world = self.comm.engine.lib.wunet_comm_world(self.comm.handle)
+            transport = "libwunet_hip wunet_comm_* (RCCL bound at run time)"
+        else:
+            world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+            transport = "torch.distributed " + (dist.get_backend(self.group) if dist.is_initialized() else "-")
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                    # noqa: BLE001 - a CPU build has none
+            ver = None
+        return {"world": world, "transport": transport, "rccl_version": ver, "bucket_bytes": [4 * (fe - fb) for _, _, fb, fe in rs],
+                "bucket_layers": [[lb, le] for lb, le, _, _ in rs], "scale": "1/world in the Adam step" if self.scale_in_optimizer else "per bucket"}
