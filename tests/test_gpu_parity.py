@@ -217,8 +217,9 @@ def test_full_size_properties(pkg, dev):
     # worst tensor-relative distance over all gradient tensors and three input seeds): the reference's own fp32 CPU arithmetic sits
     # 3.3e-3 from a float64 run of the same step, the exact-fp32 MFMA kernels 7.9e-3, the split kernels 7.8e-3 (8.2e-3 / 7.9e-3 from
     # the reference itself) - 25 BatchNorm-backward passes amplify fp32 rounding to that level on the smallest tensors whichever
-    # arithmetic runs, while the absolute error stays at 3e-6 (bar 1e-4).  The relative bar is 2.5 x the measured worst case.
-    REL_BAR = 2.0e-2
+    # arithmetic runs, while the absolute error stays at 3e-6 (bar 1e-4).  The relative bar: 1.0e-2 = 1.25 x the worst case of that
+    # table (any arithmetic, any of its seeds) and 2.4 x what this test's own batch measures (4.1e-3, split path).
+    REL_BAR = 1.0e-2
     worst_rel = 0.0
     for k, p in m.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("out"):
@@ -1042,8 +1043,8 @@ def _global_grad_err(grads, ref_grads):
     return (num / max(den, 1e-300)) ** 0.5
 
 
-@pytest.mark.parametrize("n,ci,B,T,mode", [(16, 24, 4, 65536, 3), (12, 24, 4, 16384, 3), (3, 16, 3, 1024, 4)],
-                         ids=["deep16x65536", "12x16384", "forced-small"])
+@pytest.mark.parametrize("n,ci,B,T,mode", [(16, 24, 4, 65536, 3), (16, 24, 32, 65536, 3), (12, 24, 4, 16384, 3), (3, 16, 3, 1024, 4)],
+                         ids=["deep16x65536", "deep16x65536-batch32", "12x16384", "forced-small"])      # batch 32: the size bench.py's deep16_bf16 runs (BASELINE configs[4])
 def test_bf16_mode_vs_reference_under_autocast(pkg, dev, n, ci, B, T, mode):
     """wunet_set_h3(ctx, 3): bf16 operands, one MFMA pass (tests/test_bf16_mode.py states the bar): against the reference's
     fp32 ATen CPU run the error must not exceed what the reference's own bf16 arithmetic (its forward under
