@@ -450,6 +450,23 @@ def main():
     extras = None
     if rank == 0 and world == 1 and args.mode == "train" and default_net and not args.no_extras:
         extras = {}
+        # the contract's K = 20 steps are a 0.1 s window; 200 back-to-back steps and the median of 200 event-timed steps of the SAME step
+        # function resolve a 1 - 2 % change (the boxes of the pool differ by more than that: compare within one run)
+        torch.cuda.synchronize()
+        t_l = time.perf_counter()
+        for _ in range(200):
+            step()
+        torch.cuda.synchronize()
+        long_ms = (time.perf_counter() - t_l) / 200 * 1e3
+        per = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); step(); e1.record(); e1.synchronize()
+            per.append(e0.elapsed_time(e1))
+        per.sort()
+        extras["steps200"] = {"what": "the headline step, 200 back-to-back steps / median and quartiles of 200 steps timed one by one with device events",
+                              "ms_per_step": long_ms, "frames_per_s": args.batch / long_ms * 1e3,
+                              "ms_per_step_median": per[100], "ms_per_step_p25": per[50], "ms_per_step_p75": per[150]}
         # (first, while the allocator still holds the headline run's blocks: every forward takes its workspace from torch)
         model.eval()
 

@@ -12,7 +12,7 @@ pmc_only = "--pmc-only" in sys.argv[2:]
 F, P = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
 for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.json", "bench_gemm_bf16.json"), ("pmc_sq.txt", "pmc_sq.txt"), ("step_timeline.txt", "step_timeline.txt"), ("traffic_by_family.txt", "traffic_by_family.txt"),
                  ("bench_native_rccl_eager.json", "bench_native_rccl_eager.json"),
-                 ("bench_native_rccl_graph.json", "bench_native_rccl_graph.json"), ("bench_graph.json", "bench_graph.json"),
+                 ("bench_native_rccl_graph.json", "bench_native_rccl_graph.json"), ("bench_graph.json", "bench_graph.json"), ("bench_eager.json", "bench_eager.json"),
                  ("bench_deep16_split.json", "bench_deep16_split.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"),
                  ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),

@@ -1,6 +1,6 @@
 """Random-shape check of the forced fp16-split path in the CPU emulator against the oracle (not part of the test suite):
    python tools/fuzz_emu.py [seed] [trials]      # from the repo root; prints one line per configuration, "bad: 0" at the end
-Bars: output 5e-5 absolute; worst gradient 5e-2 of that tensor's maximum (small nets sit on LeakyReLU kinks)."""
+Bars: output 5e-5 absolute; worst gradient 5e-2 of that tensor's maximum (small nets sit on LeakyReLU kinks, HISTORY.md section 7)."""
 import sys, importlib, os, time
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import numpy as np, torch

@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage (GPU box, through gpurun): TAG=r3 tools/measure_round.sh            -> gpurun_out/final/*
+# usage (GPU box, through gpurun): TAG=r4 tools/measure_round.sh            -> gpurun_out/final/*
 # Every measurement DESIGN.md / profiles/ quote for the round: PMC passes for HBM traffic (FETCH_SIZE and WRITE_SIZE in separate runs,
 # --kernel-trace only) of the headline workload and of the two extras that carry their own roofline (exact fp32, configs[4] bf16),
 # the SQ / GRBM counter passes (matrix-pipe utilisation, effective clock), the default bench line, rocprofv3 stats (concurrent and
 # one-stream).  tools/collect_round.py <tag> then copies the summaries into profiles/ and rebuilds profiles/pmc_traffic.json
 # (stamped with the source hash) here.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
-TAG=${TAG:-r3}
+TAG=${TAG:-r4}
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
     local name=$1; shift
@@ -54,7 +54,8 @@ timeout 200 python bench.py --gemm bf16 --no-cpu-baseline --no-extras > $O/bench
 # the collectives' cost inside the step on one GPU (world size 1 through the library's RCCL entry), eager and as one captured graph
 timeout 200 python bench.py --native-rccl --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_eager.json 2>/dev/null
 timeout 200 python bench.py --native-rccl --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_graph.json 2>/dev/null
-timeout 200 python bench.py --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_graph.json 2>/dev/null
+timeout 200 python bench.py --graph on --no-cpu-baseline --no-extras --no-roofline --steps 100 > $O/bench_graph.json 2>/dev/null
+timeout 200 python bench.py --graph off --no-cpu-baseline --no-extras --no-roofline --steps 100 > $O/bench_eager.json 2>/dev/null
 # (the training soak - three seeds, 100 / 300 / 600 steps, split against exact fp32 and the summation-order control - is profiles/r3_training_soak.txt,
 #  measured by its own calls: bench.py --seed S --steps N --warmup 0 [--gemm fp32] with WUNET_BENCH_NO_MEDIAN=1)
 cd /tmp

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Shader clock and socket power sampled by rocm-smi while long launches of tools/microbench/dma_issue.hip (MFMAs only / LDS-DMA from L2 / from HBM / both) and
-# bench.py's training and eval-forward steps run: the evidence behind "the matrix pipe's ceiling is a power limit" (DESIGN.md section 9).
+# bench.py's training and eval-forward steps run: the evidence behind "the matrix pipe's ceiling is a power limit" (HISTORY.md section 9).
 # GPU box; writes gpurun_out/power_probe.txt
 cd "$(dirname "$0")/.."
 mkdir -p gpurun_out; OUT=gpurun_out/power_probe.txt; : > $OUT

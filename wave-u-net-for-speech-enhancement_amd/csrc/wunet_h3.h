@@ -29,7 +29,7 @@ static __device__ __attribute__((aligned(16))) const unsigned wunet_zero16[8] = 
 // [split][B][Cout][L], summed by conv_reduce_bn_kernel / split_sum_kernel like the fp32 path.  Per stage the block stages the W sub-tile (and, for
 // the first tap group of a chunk, the x tile: 4 channel groups x 272 columns, hi and lo) and each wave issues
 // 5 taps x M_REP x 4 tiles x 3 MFMAs.  The kernel is conv_h3d_kernel (wunet_h3d.h); its register-staged predecessor and the
-// paired-tile variant of round 1 / 2 are gone (measurements: DESIGN.md sections 7, 8).
+// paired-tile variant of round 1 / 2 are gone (measurements: HISTORY.md sections 7, 8).
 struct ConvH3Args {
     const wunet_half* xh; const wunet_half* xl;   // [B][C8][L][8]
     const wunet_half* wh; const wunet_half* wl;   // packed

@@ -280,7 +280,7 @@ void plan_h3_wgrad(LayerPlan& l, int B)
     l.h3w_mblocks = round_up(mt, l.h3w_mrep) / l.h3w_mrep;
     l.h3w_nblocks = (l.cin + cib - 1) / cib;
     // 128 positions per K chunk (256 measured 5-8 % faster for the kernel alone and slower in the concurrent step, 64-position
-    // double-buffered chunks neutral: DESIGN.md sections 7, 8)
+    // double-buffered chunks neutral: HISTORY.md sections 7, 8)
     l.h3w_tp = 128;
     // wgrad_h3d_kernel<.., false> (single LDS buffer, two blocks per CU) where its registers allow: k5 up to 4 m-tiles, k15 up to 3
     const bool sb2 = l.L >= 128 && ((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
