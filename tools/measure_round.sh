@@ -52,7 +52,7 @@ WUNET_BENCH_ALL=1 timeout 200 python bench.py --no-cpu-baseline --no-extras > $O
 python tools/traffic_table.py $O/bench_all_kernels.json > $O/traffic_by_family.txt 2>&1
 timeout 200 python bench.py --gemm bf16 --no-cpu-baseline --no-extras > $O/bench_bf16.json 2>/dev/null
 # the collectives' cost inside the step on one GPU (world size 1 through the library's RCCL entry), eager and as one captured graph
-timeout 200 python bench.py --native-rccl --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_eager.json 2>/dev/null
+timeout 200 python bench.py --native-rccl --graph off --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_eager.json 2>/dev/null
 timeout 200 python bench.py --native-rccl --graph on --no-cpu-baseline --no-extras --no-roofline > $O/bench_native_rccl_graph.json 2>/dev/null
 timeout 200 python bench.py --graph on --no-cpu-baseline --no-extras --no-roofline --steps 100 > $O/bench_graph.json 2>/dev/null
 timeout 200 python bench.py --graph off --no-cpu-baseline --no-extras --no-roofline --steps 100 > $O/bench_eager.json 2>/dev/null
