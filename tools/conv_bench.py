@@ -155,6 +155,18 @@ def main():
                 d = np.diff(t, axis=1)
                 print(f"trace {name} [{cfg}] blocks {len(t)} stamps/block {ns}: block span median {np.median(t[:, -1] - t[:, 0]):.0f} ticks; "
                       f"median deltas between stamps (ticks): " + " ".join("%d" % v for v in np.median(d, axis=0)), flush=True)
+                if os.environ.get("WUNET_TRACE_REALTIME"):
+                    # library built with -DWUNET_TRACE_REALTIME (tools/_lib_rt.so): stamps are the 100 MHz counter every XCD shares
+                    full = tr.cpu().numpy().reshape(nblk, 64)
+                    rows_ = full[(full > 0).sum(axis=1) >= 3]
+                    cnt = (rows_ > 0).sum(axis=1)
+                    first = rows_[:, 0].astype(np.float64)
+                    lastv = np.array([r[c - 1] for r, c in zip(rows_, cnt)], dtype=np.float64)
+                    t00 = first.min()
+                    so = np.sort(first - t00) / 100.0
+                    print(f"      realtime: {len(rows_)} blocks; first start -> last end {(lastv.max() - t00) / 100.0:.2f} us; block starts (us after the first) "
+                          f"median {np.median(so):.2f} p90 {so[int(0.9 * (len(so) - 1))]:.2f} max {so[-1]:.2f}; block spans (us) median {np.median(lastv - first) / 100.0:.2f} "
+                          f"max {np.max(lastv - first) / 100.0:.2f}; ends (us after the first start) median {np.median(lastv - t00) / 100.0:.2f}", flush=True)
 
 
 if __name__ == "__main__":

@@ -166,7 +166,12 @@ __device__ __forceinline__ void wunet_wait_lds_barrier_if(int pred)       // (pr
     pred = __builtin_amdgcn_readfirstlane(pred);
     asm volatile("s_cmp_lg_u32 %0, 0\n\ts_cbranch_scc0 .Lwunet_nobar%=\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n.Lwunet_nobar%=:" :: "s"(pred) : "memory", "scc");
 }
+// (tools/conv_bench.py --trace-realtime builds with WUNET_TRACE_REALTIME: the 100 MHz counter all XCDs share, for block START times)
+#ifdef WUNET_TRACE_REALTIME
+__device__ __forceinline__ unsigned long long wunet_memtime() { return __builtin_amdgcn_s_memrealtime(); }
+#else
 __device__ __forceinline__ unsigned long long wunet_memtime() { return __builtin_amdgcn_s_memtime(); }
+#endif
 // nothing is scheduled across this point (hipcc otherwise sinks LDS prefetches to their first use)
 #define wunet_sched_fence() __builtin_amdgcn_sched_barrier(0)
 // the value becomes opaque to the optimiser (no hoisting of what is derived from it)

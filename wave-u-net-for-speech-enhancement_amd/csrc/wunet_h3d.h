@@ -151,7 +151,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
 #define WUNET_H3D_STAMP(K_)                                                                                       \
     if (A.trace) {                                                                                                       \
         const unsigned long long t_ = wunet_memtime();                                                            \
-        if (tid == 0 && (K_) < 64) A.trace[(size_t)blockIdx.x * 64 + (K_)] = t_;                                  \
+        if (tid == 0 && (K_) < 64) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (K_)] = t_;                                  \
     }
 
     const int G = gridDim.x, nitems = A.ntiles * A.mblocks;

@@ -135,11 +135,11 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
     snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)));
-    const int npl = bf ? 1 : 2;
-    const size_t smem = (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4) * sizeof(float);
+    const size_t smem = h3d_smem(nseg, mrep, bf);
     const int nitems = a.ntiles * a.mblocks;
-    int gx = h3_grid_cap() / ksplit;
-    gx &= ~7;
+    // resident blocks: two per CU, one for the 16-segment tile (96 KB); a K-split layer whose items x splits fit them runs one item per block
+    int gx = h3_grid_cap() / 2 * h3d_blocks_per_cu(nseg, mrep, bf) / ksplit;
+    if (gx < nitems) gx &= ~7;
     if (gx < 8) gx = 8;
     if (gx > nitems) gx = nitems;
     const dim3 grid((unsigned)gx, (unsigned)ksplit);

@@ -217,14 +217,41 @@ size_t h3w_part_stride(const LayerPlan& l)
     return (size_t)l.h3w_mblocks * l.h3w_nblocks * WUNET_WAVES * l.h3w_mrep * tw * 256;
 }
 
-// conv_h3d_kernel split-K: with fewer than ~1.5 blocks per CU the K stages are split so that about two blocks per CU
-// exist; returns the stages per split (== nstage: no split).
-int h3_stages_per_split(int blocks, int nstage)
+// dynamic LDS of one conv_h3d_kernel block: x tile [planes][4][NSEG * (256 / NSEG + 16)] + W sub-tile [planes][M_REP][5][64] pieces of 16 bytes
+// + the statistics hand-over
+size_t h3d_smem(int nseg, int mrep, int bf)
 {
-    if (blocks >= 384 || nstage <= 1 || getenv("WUNET_H3_NOSPLIT")) return nstage;      // (switch: tests reach the un-split epilogue on small shapes)
-    int ks = (512 + blocks - 1) / blocks;
-    if (ks > nstage) ks = nstage;
-    return (nstage + ks - 1) / ks;
+    const int npl = bf ? 1 : 2;
+    return (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4) * sizeof(float);
+}
+// blocks of that size a CU holds (launch bounds: two; the 16-segment tile's 96 KB: one)
+int h3d_blocks_per_cu(int nseg, int mrep, int bf) { return 2 * h3d_smem(nseg, mrep, bf) <= 160u * 1024u ? 2 : 1; }
+
+// conv_h3d_kernel split-K of the levels with fewer work items than resident blocks: the K stages are split so that ONE round of
+// resident blocks covers the layer, every block with (nearly) the same number of stages.  Round 4's block start / end times
+// (tools/conv_bench.py --trace on the real-time counter) showed what the old rule (about 512 blocks, whatever fits) cost: the
+// 16-sample levels hold one 96 KB block per CU, so 288 / 432 blocks ran in two rounds (19 us instead of 10); at 64 samples 96
+// persistent blocks walked 112 items, 16 of them two (24 us instead of 13).  Cost of a candidate = rounds x (fixed part of a block:
+// first fetch + epilogue, about 5 us, + 1.8 us per stage) + the partial sums the reduce kernel reads; returns the stages per split
+// (== nstage: no split).
+int h3_stages_per_split(int items, int nstage, int slots)
+{
+    if (items >= 384 || nstage <= 1 || getenv("WUNET_H3_NOSPLIT")) return nstage;      // (switch: tests reach the un-split epilogue on small shapes)
+    if (getenv("WUNET_H3_OLDSPLIT")) {              // A/B switch: the rule of rounds 1 - 3
+        int ks = (512 + items - 1) / items;
+        if (ks > nstage) ks = nstage;
+        return (nstage + ks - 1) / ks;
+    }
+    int best_sps = nstage;
+    double best = 1e30;
+    for (int sps = nstage; sps >= 1; --sps) {
+        const int ks = (nstage + sps - 1) / sps;
+        const long long blocks = (long long)items * ks;
+        const long long rounds = (blocks + slots - 1) / slots;
+        const double cost = (double)rounds * (5.0 + 1.8 * sps) + 0.12 * ks;
+        if (cost < best - 1e-9) { best = cost; best_sps = sps; }
+    }
+    return best_sps;
 }
 
 // K tail of conv_h3d_kernel: with c8 = 4 nfull + t1 groups of 8 K channels, the t1 left-over groups run one tail stage each (the taps
@@ -258,9 +285,10 @@ H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* o
     p.nch = (c8 + 3) / 4;
     p.ntt = (p.mrep < 4 && L >= 32) ? h3_tail_steps(kch, taps) : 0;      // (WUNET_H3D_HAS_TAIL: the shapes at the register limit go without)
     const int ns = h3_stage_count(kch, taps, p.ntt);
-    p.sps = h3_stages_per_split(p.ntiles * (p.mtp / p.mrep), ns);
+    const int nseg = L >= 256 ? 1 : 256 / L;
+    p.sps = h3_stages_per_split(p.ntiles * (p.mtp / p.mrep), ns, 256 * h3d_blocks_per_cu(nseg, p.mrep, bf));
     p.ksplit = (ns + p.sps - 1) / p.sps;
-    (void)ntg; (void)bf;
+    (void)ntg;
     return p;
 }
 
