@@ -1,0 +1,376 @@
+// conv_h3w8_kernel: conv_h3d_kernel's GEMM (same LDS images, same fragments, same order of the MFMAs of every accumulator: bit-identical
+// results) as ONE block of EIGHT waves per CU - the structural alternative VERDICT r3 #4 asked to be tested:
+//   * waves 0-3 / 4-7 (row groups) compute two adjacent row blocks of 16 * M_REP rows over the SAME 256-position tile: one x tile in LDS
+//     serves 32 * M_REP rows, the x DMA per MFMA halves (every wave issues half the x pieces);
+//   * the W image is double-buffered (2 x 2 row groups x 30 KB): the next stage's W is issued at the top of the stage, no release barrier
+//     inside the taps; the x tile is handed back after the up-front B-fragment reads as before.  34 + 4 x 30 + 3 KB = 157 KB of the 160;
+//   * two barriers per stage (top: everything landed; after the B fragments: x free) instead of three.
+// Un-segmented levels (L >= 256), two planes (no bf16 mode), M_REP <= 3.  WUNET_H3_RG=2 selects it where the planner allows.
+#pragma once
+#include "wunet_h3d.h"
+#undef WUNET_H3D_VALID
+#undef WUNET_H3D_X_PIECE
+
+
+
+template <int TAPS, int M_REP>
+__global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3w8_kernel(ConvH3Args A)
+{
+    constexpr int NSEG = 1, NW = 8;
+    constexpr bool BF = false;
+    static_assert(M_REP <= 3, "two W buffers of two row groups within the LDS");
+    constexpr int PAD = TAPS / 2;
+    constexpr int TG = 5;                         // taps per stage
+    constexpr int NTG = TAPS / TG;
+    constexpr int LSEG = 256 / NSEG, SW = LSEG + 16;
+    constexpr int COLS = NSEG * SW, Q4 = COLS / 4;
+    constexpr int NPL = BF ? 1 : 2;
+    constexpr int XP = NPL * 4 * COLS;            // 16-byte pieces of the x tile
+    constexpr int WPM = TG * 64;
+    constexpr int WP = NPL * M_REP * WPM;         // pieces of the W sub-tile of a stage
+    static_assert(XP % 64 == 0 && WP % 64 == 0, "whole DMA instructions per wave");
+    WUNET_DYN_SMEM(smem);
+    wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS, de-interleaved][8]
+    wunet_half* ws = xs + XP * 8;                                      // [2 buffers][2 row groups][hi|lo][M_REP][TG][4][16][8]
+    float* red = reinterpret_cast<float*>(ws + 4 * WP * 8);            // [8 waves][M_REP * 16][2] statistics hand-over, + 8 maxima
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
+    const int pw = wave & 3, rg = wave >> 2, tid_rg = tid & (WUNET_THREADS - 1);      // position quarter, row group, thread within the group
+    const int L = A.L;
+
+    // ---- per-thread source descriptors of its DMA pieces (independent of the work item).  A DMA instruction of a wave writes one
+    // RUN of 64 consecutive pieces; the runs of the x image ([plane][4 groups][COLS, de-interleaved]: RP runs per plane) are dealt
+    // so that the plane of an instruction is a compile-time constant: instruction it < NPL*XF covers runs 4 (it % XF) + wave of
+    // plane it / XF, the XR left-over runs of every plane share one last instruction (wave -> plane wave / XR, run 4 XF + wave % XR).
+    // Piece p of a plane is (channel group c8 = p / COLS, column col = 4 (w % Q4) + w / Q4 with w = p % COLS - the de-interleave).
+    // Kept per piece: xoffb = bytes from 8 samples in front of the tile's first sample in the chunk's first channel group of the hi
+    // plane (never negative: the DMA takes an SGPR base + an unsigned 32-bit offset per lane; the lo plane lies A.xdelta bytes behind
+    // the hi plane and is part of the offset); per thread, one bit per
+    // piece: m_live (the wave has a run in the shared instruction), m_lo / m_hi (the piece is left / right halo: outside the item
+    // for the first / last tile of an item, always for NSEG > 1), m_pl (plane of the shared instruction); c8pk / segpk = the
+    // piece's channel group (2 bits) / item of the tile (4 bits).
+    constexpr int RP = 4 * COLS / 64, XF = RP / NW, XR = RP % NW;
+    constexpr int XIT = NPL * XF + (XR ? 1 : 0);
+    static_assert(XR * NPL <= NW, "left-over runs fit one instruction");
+    static_assert(XIT <= 16, "descriptor bit fields");
+    int xoffb[XIT];
+    unsigned m_live = 0, m_lo = 0, m_hi = 0, m_pl = 0, c8pk = 0;
+    unsigned long long segpk = 0;
+    int xrun = 0;                                   // run (within its plane) of this wave in the last, shared instruction
+#pragma unroll
+    for (int it = 0; it < XIT; ++it) {
+        int pl = it / XF, run = NW * (it % XF) + wave;
+        bool live = true;
+        if (it == NPL * XF) { pl = wave / (XR ? XR : 1); run = NW * XF + wave % (XR ? XR : 1); live = wave < XR * NPL; xrun = run; }
+        const int p = run * 64 + lane, c8 = p / COLS, w = p % COLS;
+        const int col = 4 * (w % Q4) + w / Q4, seg = col / SW, lrel = col - seg * SW - 8;
+        xoffb[it] = ((seg * A.C8 + c8) * L + lrel + 8) * 16 + (NPL > 1 && (pl & 1) ? (int)A.xdelta : 0);
+        m_live |= (unsigned)live << it;
+        m_lo |= (unsigned)(lrel < 0) << it;
+        m_hi |= (unsigned)(lrel >= LSEG) << it;
+        m_pl |= (unsigned)(pl & 1) << it;
+        c8pk |= (unsigned)c8 << (2 * it);
+        segpk |= (unsigned long long)seg << (4 * it);
+    }
+    // W sub-tile [hi|lo][M_REP][TG][64 pieces]: per (plane, m-tile) a contiguous run of TG * 64 = 320 pieces in the pack and in the LDS
+    // image alike - one DMA instruction of all four waves (pieces 0 .. 255, lane offset 16 tid) plus one of a single wave (pieces
+    // 256 .. 319); the run's start is a scalar.  Two per-lane offsets serve every W piece of the kernel.
+    static_assert(WPM == 320, "W run = 256 + 64 pieces");
+    const unsigned wo_all = (unsigned)tid_rg * 16u, wo_rest = (256u + (unsigned)lane) * 16u;
+    const wunet_lds_t xs_a = wunet_lds_addr(xs), ws_a = wunet_lds_addr(ws);
+    const int wave_u = wunet_uniform(wave), pw_u = wunet_uniform(pw), rg_u = wunet_uniform(rg);
+    // pieces of the tile that lie inside the tensor: bit per piece.  Halo pieces of an item's first / last tile (every halo piece
+    // for NSEG > 1: each item of the tile carries its own zero padding), items beyond the batch, channel groups beyond C8 (only the
+    // last chunk can have them: the test is skipped elsewhere)
+#define WUNET_H3D_VALID(B_, L0_, CH_, OUT_)                                                                       \
+    unsigned OUT_ = m_live;                                                                                       \
+    {                                                                                                             \
+        if (NSEG > 1 || (L0_) == 0) OUT_ &= ~m_lo;                                                                \
+        if (NSEG > 1 || (L0_) + 256 >= L) OUT_ &= ~m_hi;                                                          \
+        if (NSEG > 1 && (B_) + NSEG > A.B) {                                                                      \
+            _Pragma("unroll") for (int it = 0; it < XIT; ++it)                                                    \
+                if ((B_) + (int)((segpk >> (4 * it)) & 15) >= A.B) OUT_ &= ~(1u << it);                           \
+        }                                                                                                         \
+        if ((CH_) * 4 + 4 > A.C8) {                                                                               \
+            _Pragma("unroll") for (int it = 0; it < XIT; ++it)                                                    \
+                if ((CH_) * 4 + (int)((c8pk >> (2 * it)) & 3) >= A.C8) OUT_ &= ~(1u << it);                       \
+        }                                                                                                         \
+    }
+    // A piece: SGPR base of the tile (+ stage) + the piece's stage-invariant 32-bit offset; a piece outside the tensor takes the offset of
+    // the operand's 16-byte zero pad (A.zpad, behind both planes) instead.  No 64-bit address per lane, nothing for hipcc to hoist.
+#define WUNET_H3D_X_PIECE(IT_, VALID_, BASE_, ZSEL_)                                                              \
+    {                                                                                                             \
+        const unsigned o_ = (((VALID_) >> (IT_)) & 1) ? (unsigned)xoffb[IT_] : (ZSEL_);                            \
+        const int run_ = (IT_) < NPL * XF ? NW * ((IT_) % XF) + wave_u : wunet_uniform(xrun);                     \
+        const int pl_ = (IT_) < NPL * XF ? (IT_) / XF : wunet_uniform((m_pl >> (IT_)) & 1);                       \
+        wunet_dma16s(BASE_, o_, xs_a + (pl_ * 4 * COLS + run_ * 64) * 16);                                        \
+    }
+#define WUNET_H3D_ISSUE_X(B_, L0_, CH_)                                                                           \
+    {                                                                                                             \
+        const char* const base_ = reinterpret_cast<const char*>(A.xh) + (long long)((((size_t)(B_) * A.C8 + (CH_) * 4) * L + (L0_)) * 16) - 128; \
+        const unsigned zsel_ = (unsigned)(reinterpret_cast<const char*>(A.zpad) - base_);                         \
+        WUNET_H3D_VALID(B_, L0_, CH_, valid_)                                                                     \
+        _Pragma("unroll") for (int it = 0; it < XIT; ++it) {                                                      \
+            if (it < NPL * XF) WUNET_H3D_X_PIECE(it, valid_, base_, zsel_)                                        \
+            else if ((m_live >> it) & 1) WUNET_H3D_X_PIECE(it, valid_, base_, zsel_)                              \
+        }                                                                                                         \
+    }
+#define WUNET_H3D_ISSUE_W(MT0_, ST_, BUF_, ACT_)                                                                  \
+    if (ACT_) {                                                                                                    \
+        const char* const base_ = reinterpret_cast<const char*>(A.wh) + (long long)((((size_t)(MT0_) * A.NS + (ST_)) * TG * 64) * 16); \
+        const wunet_lds_t dst_ = ws_a + (((BUF_) * 2 + rg_u) * WP) * 16;                                          \
+        _Pragma("unroll") for (int sub = 0; sub < NPL * M_REP; ++sub) {                                           \
+            const char* const run_ = base_ + (long long)(sub % M_REP) * A.NS * (TG * 64 * 16) + (sub >= M_REP ? (long long)A.wdelta : 0LL); \
+            wunet_dma16s(run_, wo_all, dst_ + (sub * WPM + pw_u * 64) * 16);                                      \
+            if (pw_u == (sub & 3)) wunet_dma16s(run_, wo_rest, dst_ + (sub * WPM + 256) * 16);                    \
+        }                                                                                                         \
+    }
+    // work item v -> (position tile, PAIR of row blocks): the pairs of one tile on ONE XCD (they share its x tile in that L2);
+    // gridDim.x is a multiple of 8 whenever a block walks more than one item, so the XCD of an item is the block's
+#define WUNET_H3D_ITEM(V_, TILE_, MBLK_)                                                                          \
+    if ((A.ntiles & 7) == 0) {                                                                                    \
+        const int xcd_ = (V_) & 7, k_ = (V_) >> 3;                                                                \
+        MBLK_ = k_ % mpairs;                                                                                      \
+        TILE_ = (k_ / mpairs) * 8 + xcd_;                                                                         \
+    } else {                                                                                                      \
+        MBLK_ = (V_) % mpairs;                                                                                    \
+        TILE_ = (V_) / mpairs;                                                                                    \
+    }
+#define WUNET_H3D_STAMP(K_)                                                                                       \
+    if (A.trace) {                                                                                                       \
+        const unsigned long long t_ = wunet_memtime();                                                            \
+        if (tid == 0 && (K_) < 64) A.trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + (K_)] = t_;                                  \
+    }
+
+    const int mpairs = (A.mblocks + 1) >> 1;
+    const int G = gridDim.x, nitems = A.ntiles * mpairs;
+    int v = blockIdx.x;
+    if (v >= nitems) return;
+    int tile, mblk;
+    WUNET_H3D_ITEM(v, tile, mblk)
+    int b = (tile * 256) >> A.logL, l0 = NSEG == 1 ? ((tile * 256) & (L - 1)) : 0, mt0 = (mblk * 2 + rg_u) * M_REP;
+    bool act = mblk * 2 + rg_u < A.mblocks;            // (an odd number of row blocks: the last pair's second group only keeps the barriers)
+    int wb = 0;                                        // W buffer of the current stage
+    const bool split = gridDim.y > 1;
+    const int st_beg = blockIdx.y * A.stages_per_split;
+    const int nstage = (st_beg + A.stages_per_split < A.NS) ? st_beg + A.stages_per_split : A.NS;
+    constexpr bool KT = true;
+    const int nfs = KT ? A.NFS : 0x7fffffff, tch = nfs / NTG;        // full stages (TG taps of a chunk of 4 channel groups); the tail stages' chunk
+    constexpr int NTT = (TAPS + 3) / 4;            // steps of a tail stage
+    int stamp = 0;
+    float amax_run = 0.0f;                          // eval mode: the block's running maximum of the activation bound over its work items
+    WUNET_H3D_STAMP(stamp) ++stamp;
+    if (st_beg < nstage) {
+        WUNET_H3D_ISSUE_X(b, l0, (!KT || st_beg < nfs ? st_beg / NTG : tch))
+        WUNET_H3D_ISSUE_W(mt0, st_beg, 0, act)
+    }
+
+    // this lane's 4 positions wave*64 + 4*i16 .. +3 lie in ONE batch item of the tile: item lseg, first sample ll0
+    const int lpos = pw * 64 + i16 * 4;
+    const int lseg = lpos / LSEG, ll0 = lpos - lseg * LSEG;
+    const int boff = (q * COLS + ((lseg * SW + ll0) >> 2)) * 8;
+    const int boff_t = ((lseg * SW + ll0) >> 2) * 8;        // tail stages: + the group's plane
+    const int aoff = (q * 16 + i16) * 8;
+
+    for (;;) {
+        const bool more = v + G < nitems;
+        int ntile = 0, nmblk = 0;
+        if (more) { WUNET_H3D_ITEM(v + G, ntile, nmblk) }
+        const int nb = (ntile * 256) >> A.logL, nl0 = NSEG == 1 ? ((ntile * 256) & (L - 1)) : 0, nmt0 = (nmblk * 2 + rg_u) * M_REP;
+        const bool nact = nmblk * 2 + rg_u < A.mblocks;
+
+        wunet_f4 acc[M_REP][4];
+#pragma unroll
+        for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
+        for (int st = st_beg; st < nstage; ++st) {
+            const bool tail = KT && st >= nfs;
+            const int ch = tail ? tch : st / NTG, tg = tail ? st - nfs : st - ch * NTG;     // (tail: tg = the group of its chunk)
+            const bool last = st + 1 == nstage, has_next = !last || more;
+            const int nst = last ? st_beg : st + 1, nch = (!KT || nst < nfs) ? nst / NTG : tch;
+            const bool x_next = has_next && (last || nch != ch);
+            wunet_setprio(0);
+            wunet_wait_dma_barrier();             // this stage's x tile and W image have landed (every wave waited for its own pieces)
+            WUNET_H3D_STAMP(stamp) ++stamp;
+            // the other W buffer was last read in the previous stage, which every wave has left: the next stage's W goes there now
+            if (has_next) {
+                if (last) { WUNET_H3D_ISSUE_W(nmt0, nst, wb ^ 1, nact) } else { WUNET_H3D_ISSUE_W(mt0, nst, wb ^ 1, act) }
+            }
+            const wunet_half* const wsr = ws + ((wb * 2 + rg) * WP) * 8;
+            wunet_setprio(3);
+            // B fragments slide: with the interleaved column mapping fragment (n-tile nt, tap) is column 4*lane + nt + tap = F[nt + tap]
+            // (tail stage: every quarter reads the plane of the stage's group and its taps start at q * NTT; NTT + 3 fragments, the rest
+            // repeat the first).  ONE stage body for both kinds - a second copy of the MFMA block behind a branch cost 30 registers
+#define WUNET_H3D_LOAD_F(TAILS_)                                                                                  \
+    wunet_h8 fh[TG + 3], fl[TG + 3];                                                                              \
+    {                                                                                                             \
+        const int fb_ = ((TAILS_) && tail) ? boff_t + tg * COLS * 8 : boff;                                       \
+        const int e0_ = ((TAILS_) && tail) ? q * NTT : tg * TG;                                                   \
+        _Pragma("unroll") for (int e = 0; e < TG + 3; ++e) {                                                      \
+            const int ec = e0_ + ((TAILS_) && e >= NTT + 3 && tail ? 0 : e) + 8 - PAD;                            \
+            const int po = ((ec & 3) * Q4 + (ec >> 2)) * 8;                                                       \
+            fh[e] = wunet_ldh8(xs + fb_ + po);                                                                    \
+            if (!BF) fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + fb_ + po);                                            \
+        }                                                                                                         \
+    }
+            wunet_h8 ah[2][M_REP], al[2][M_REP];
+#define WUNET_H3D_LOAD_A(BUF_, TL_)                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        ah[BUF_][mt] = wunet_ldh8(wsr + ((mt * TG + (TL_)) * 64) * 8 + aoff);                                     \
+        if (!BF) al[BUF_][mt] = wunet_ldh8(wsr + ((M_REP + mt) * TG + (TL_)) * 64 * 8 + aoff);                    \
+    }
+#define WUNET_H3D_PASS(WHICH_, BUF_, TL_)                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
+            if (BF) { if ((WHICH_) == 2) acc[mt][nt] = wunet_mfma16b(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]); } \
+            else if ((WHICH_) == 0) acc[mt][nt] = wunet_mfma16h(al[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);       \
+            else if ((WHICH_) == 1) acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fl[(TL_) + nt], acc[mt][nt]);       \
+            else acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);                          \
+        }
+            // After the B fragments: the x tile is free once every wave holds them; the prefetch of the next step's A fragments is
+            // ISSUED at the fence, not sunk to its first use; with the last A fragments of the stage in flight the W sub-tile is free
+            // once every wave has them.  A tail stage runs the first NTT steps only.
+            WUNET_H3D_LOAD_F(true)
+            WUNET_H3D_LOAD_A(0, 0)
+            if (x_next) {
+                wunet_wait_lds_barrier();
+                if (last) { WUNET_H3D_ISSUE_X(nb, nl0, nch) } else { WUNET_H3D_ISSUE_X(b, l0, nch) }
+            }
+#define WUNET_H3D_STEP(TL_)                                                                                       \
+    {                                                                                                             \
+        constexpr int tl = (TL_);                                                                                 \
+        if (tl + 1 < TG) {                                                                                        \
+            if (tl & 1) { WUNET_H3D_LOAD_A(0, tl + 1) } else { WUNET_H3D_LOAD_A(1, tl + 1) }                      \
+        }                                                                                                         \
+        wunet_sched_fence();                                                                                      \
+        if (tl & 1) { WUNET_H3D_PASS(0, 1, tl) } else { WUNET_H3D_PASS(0, 0, tl) }                                \
+        if (tl & 1) { WUNET_H3D_PASS(1, 1, tl) WUNET_H3D_PASS(2, 1, tl) } else { WUNET_H3D_PASS(1, 0, tl) WUNET_H3D_PASS(2, 0, tl) } \
+    }
+            // (the steps a tail stage skips behind ONE uniform branch; TG - 2 >= NTT, 5 taps: the W sub-tile of a full stage is
+            // released inside them, that of a tail stage at its step NTT - 2)
+            static_assert(TG == 5 && (NTT == 4 || NTT == 2), "step list below");
+            if (act) {                            // (a group without rows: no MFMAs beside the other group's, only the barriers and its x pieces)
+                WUNET_H3D_STEP(0) WUNET_H3D_STEP(1)
+                if (NTT == 4) {
+                    WUNET_H3D_STEP(2) WUNET_H3D_STEP(3)
+                    if (!tail) { WUNET_H3D_STEP(4) }
+                } else if (!tail) {
+                    WUNET_H3D_STEP(2) WUNET_H3D_STEP(3) WUNET_H3D_STEP(4)
+                }
+            }
+#undef WUNET_H3D_STEP
+            WUNET_H3D_STAMP(stamp) ++stamp;
+            wb ^= 1;
+        }
+#undef WUNET_H3D_LOAD_A
+#undef WUNET_H3D_LOAD_F
+#undef WUNET_H3D_PASS
+
+        // ---- epilogue (conv_h3_kernel's): un-scale, bias, store, BN statistics of the bias-free conv; a K split stores its
+        // bias-free partial sum (statistics then come from the reduce kernel).  The DMAs of the next item's first stage are in flight.
+        wunet_setprio(0);
+        const float inv = A.sc ? A.sc[1] : 1.0f, inv2 = A.sc2 ? A.sc2[1] : 1.0f;
+        float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
+        const int bo = b + lseg;
+        float amax = 0.0f;
+        // the per-row constants in ONE batch of loads: loaded row by row where they are used, each load was waited for with
+        // vmcnt(0) - i.e. together with the previous row's store - and the 4*M_REP serialised round trips were a third of a shallow
+        // layer's block time (phase stamps, tools/conv_bench.py --trace)
+        float bvs[M_REP][4];
+#pragma unroll
+        for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = (mt0 + mt) * 16 + q * 4 + r;
+                bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+            }
+        // row (mt, r) of this lane: prow + (mt * 16 + r) * L  (uniform strides: no 64-bit multiply per row)
+        float* const prow = outp + ((size_t)bo * A.Cout + mt0 * 16 + q * 4) * L + (l0 + ll0);
+        const bool want_stats = A.stats && !split;
+        const bool full = (mt0 + M_REP) * 16 <= A.Cout && (NSEG == 1 || b + NSEG <= A.B);     // no row / item of the tile outside the tensor
+        // STATS_: Sigma, Sigma^2 of the bias-free conv per row; GUARD_: rows beyond Cout / items beyond B exist; EVAL_: the activation
+        // bound of eval mode.  Copies of the loop behind uniform branches: the un-guarded, statistics-free one (data gradients, K
+        // splits) is half the instructions
+#define WUNET_H3D_ROWS(STATS_, GUARD_, EVAL_)                                                                     \
+    float eas[M_REP][4], ess[M_REP][4];                                                                           \
+    if (EVAL_) {                                                  /* one batch of loads, like the biases */      \
+        _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+                const int co = (mt0 + mt) * 16 + q * 4 + r;                                                       \
+                eas[mt][r] = co < A.Cout ? A.ev_a[co] : 0.0f;                                                     \
+                ess[mt][r] = co < A.Cout ? A.ev_s[co] : 0.0f;                                                     \
+            }                                                                                                     \
+    }                                                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
+            const int co = (mt0 + mt) * 16 + q * 4 + r;                                                           \
+            const float bv = bvs[mt][r];                                                                          \
+            wunet_f4 o;                                                                                           \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
+                const float vv = acc[mt][nt][r] * inv * inv2;                                                     \
+                if (STATS_) { s1[r] += vv; s2[r] = fmaf(vv, vv, s2[r]); }                                                    \
+                o[nt] = vv + bv;                                                                                  \
+            }                                                                                                     \
+            if (!(GUARD_) || (co < A.Cout && bo < A.B)) {                                                         \
+                wunet_st4(prow + (size_t)(mt * 16 + r) * L, o);                                                   \
+                if (EVAL_) {                                                                                      \
+                    const float ea = eas[mt][r], es = ess[mt][r];                                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));  \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (STATS_) {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+                s1[r] = wunet_row16_sum(s1[r]);                                                                   \
+                s2[r] = wunet_row16_sum(s2[r]);                                                                   \
+                if (i16 == 0) {                               /* per-wave sums of row mt*16 + q*4 + r -> LDS */   \
+                    float* rp = red + ((wave * M_REP + mt) * 16 + q * 4 + r) * 2;                                 \
+                    rp[0] = s1[r];                                                                                \
+                    rp[1] = s2[r];                                                                                \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+        if (A.xrows) { WUNET_H3D_ROWS(false, true, true) }          // eval mode: the maximum of the activation bound instead of statistics
+        else if (want_stats) { if (full) { WUNET_H3D_ROWS(true, false, false) } else { WUNET_H3D_ROWS(true, true, false) } }
+        else { if (full) { WUNET_H3D_ROWS(false, false, false) } else { WUNET_H3D_ROWS(false, true, false) } }
+#undef WUNET_H3D_ROWS
+        if (A.xrows) {                            // eval: block maximum of the activation bound (max is order independent)
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
+            float* rp = red + NW * M_REP * 32;
+            if (lane == 0) rp[wave] = amax;
+            wunet_wait_lds_barrier();
+            if (tid == 0) amax_run = fmaxf(amax_run, fmaxf(fmaxf(fmaxf(rp[0], rp[1]), fmaxf(rp[2], rp[3])), fmaxf(fmaxf(rp[4], rp[5]), fmaxf(rp[6], rp[7]))));
+        }
+        // one statistics row per tile (256 positions): the four waves' sums are added in wave order
+        if (A.stats && !split) {
+            wunet_wait_lds_barrier();
+            if (tid_rg < M_REP * 16) {
+                const float* rp = red + (rg * 4 * M_REP * 16 + tid_rg) * 2;
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WUNET_WAVES; ++w) {
+                    t1 += rp[w * M_REP * 32];
+                    t2 += rp[w * M_REP * 32 + 1];
+                }
+                const int co = mt0 * 16 + tid_rg;
+                if (co < A.Cout) {
+                    float* stp = A.stats + ((size_t)co * A.ntiles + tile) * 2;
+                    stp[0] = t1;
+                    stp[1] = t2;
+                }
+            }
+        }
+        WUNET_H3D_STAMP(stamp) ++stamp;
+        if (!more) break;
+        v += G; tile = ntile; b = nb; l0 = nl0; mt0 = nmt0; act = nact;
+    }
+    if (A.xrows && tid == 0) wunet_atomic_absmax(A.xrows, amax_run);      // ONE atomic per block into the layer's xb slot
+#undef WUNET_H3D_ISSUE_X
+#undef WUNET_H3D_ISSUE_W
+#undef WUNET_H3D_ITEM
+#undef WUNET_H3D_STAMP
+}
