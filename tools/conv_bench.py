@@ -167,6 +167,10 @@ def main():
                     print(f"      realtime: {len(rows_)} blocks; first start -> last end {(lastv.max() - t00) / 100.0:.2f} us; block starts (us after the first) "
                           f"median {np.median(so):.2f} p90 {so[int(0.9 * (len(so) - 1))]:.2f} max {so[-1]:.2f}; block spans (us) median {np.median(lastv - first) / 100.0:.2f} "
                           f"max {np.max(lastv - first) / 100.0:.2f}; ends (us after the first start) median {np.median(lastv - t00) / 100.0:.2f}", flush=True)
+                    ends = (lastv - t00) / 100.0
+                    bx = np.nonzero((full > 0).sum(axis=1) >= 3)[0] % 8          # (grid.y == 1: row = blockIdx.x, XCD = blockIdx.x % 8)
+                    print("      ends by XCD (median / max us): " + "  ".join("%.1f/%.1f" % (np.median(ends[bx == k]), ends[bx == k].max()) for k in range(8) if (bx == k).any())
+                          + "; deciles of all ends: " + " ".join("%.1f" % v for v in np.quantile(ends, np.linspace(0, 1, 11))), flush=True)
 
 
 if __name__ == "__main__":
