@@ -202,7 +202,10 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             if (WUNET_ABL & 32) __syncthreads(); else
             wunet_wait_dma_barrier();             // this stage's x tile and W sub-tile have landed (every wave waited for its own pieces)
             WUNET_H3D_STAMP(stamp) ++stamp;
-            wunet_setprio(3);
+            // the two blocks of a CU take turns at the higher issue priority, stage by stage: at equal priority the older block of the pair
+            // wins every tie, finishes its items at 0.78 of the kernel and leaves its partner alone on the CU for the rest (block end times
+            // on the real-time counter, profiles/r4_conv_prio_alternate_ab.txt: bimodal 50 / 64 us -> one mode 57 - 65 us; -1.3 % kernel time)
+            if ((st + (int)(blockIdx.x >= (unsigned)(G >> 1))) & 1) wunet_setprio(3); else wunet_setprio(1);
             // B fragments slide: with the interleaved column mapping fragment (n-tile nt, tap) is column 4*lane + nt + tap = F[nt + tap]
             // (tail stage: every quarter reads the plane of the stage's group and its taps start at q * NTT; NTT + 3 fragments, the rest
             // repeat the first).  ONE stage body for both kinds - a second copy of the MFMA block behind a branch cost 30 registers
