@@ -237,6 +237,10 @@ int h3d_blocks_per_cu(int nseg, int mrep, int bf) { return 2 * h3d_smem(nseg, mr
 int h3_stages_per_split(int items, int nstage, int slots)
 {
     if (items >= 384 || nstage <= 1 || getenv("WUNET_H3_NOSPLIT")) return nstage;      // (switch: tests reach the un-split epilogue on small shapes)
+    if (const char* e = getenv("WUNET_H3_SPS")) {    // measurement hook (tools/conv_bench.py sweeps it per layer): the stages per split
+        const int v = atoi(e);
+        if (v >= 1) return v < nstage ? v : nstage;
+    }
     if (getenv("WUNET_H3_OLDSPLIT")) {              // A/B switch: the rule of rounds 1 - 3
         int ks = (512 + items - 1) / items;
         if (ks > nstage) ks = nstage;
