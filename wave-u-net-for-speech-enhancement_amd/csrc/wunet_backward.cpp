@@ -88,10 +88,14 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         }
         // the last layer on the split kernels: its g is recomputed from the head gradient by gz_split_h3_kernel (HEAD mode), not stored
         const bool head_in_gz = i == NL - 1 && i > 0 && l.h3d && !fuse && !tiny;
+        // an encoder layer on the split kernels whose two data gradients are whole tensors: g is recomputed by gz_split_h3_kernel (ENC
+        // mode) from them instead of written here and read back (WUNET_NO_ENC_GZ=1: A/B switch)
+        static const bool no_enc_gz = getenv("WUNET_NO_ENC_GZ") != nullptr;
+        const bool enc_in_gz = i > 0 && i < n && l.h3d && !fuse && !tiny && !dx_stays_split(c, i + 1) && !no_enc_gz;
         {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
             const double pe = (double)c->B * l.cout * l.L;
             const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : "pass_a_kernel<ENC>";
-            prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : i >= n ? 16.0 : 14.0) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
+            prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : i >= n ? 16.0 : (enc_in_gz ? 10.0 : 14.0)) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
         }
         if (i == NL - 1) {
             if (head_in_gz) p.gpre = nullptr;
@@ -113,6 +117,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             const LayerPlan& dc = c->ly[2 * n - i];
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + dc.dx; p.Cg0 = dc.cin; p.coff = dc.c0; p.g1 = ws + nx.dx;
+            if (enc_in_gz) p.gpre = nullptr;
             if (dx_stays_split(c, i + 1)) {
                 p.g1 = ws + c->spart_off; p.g1_splits = nx.d.ksplit; p.g1_stride = (size_t)c->B * nx.cin * nx.L;
             }
@@ -146,9 +151,13 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     const size_t nt = (size_t)c->B * c8 * (l.L / 4);
                     size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                     if (hb > 8192) hb = 8192;
-                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * ((head_in_gz ? 4.0 : 8.0) + (c->bf ? 2.0 : 4.0)));
+                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * ((head_in_gz ? 4.0 : enc_in_gz ? 10.0 : 8.0) + (c->bf ? 2.0 : 4.0)));
                     GzHeadArgs hd{};
                     if (head_in_gz) { hd.gh = ws + c->gh_off; hd.wh = params[4 * NL]; hd.a = ws + l.a; hd.s = ws + l.s; }
+                    if (enc_in_gz) {
+                        const LayerPlan& dc = c->ly[2 * n - i];
+                        hd.gd = ws + dc.dx; hd.Cg0 = dc.cin; hd.coff = dc.c0; hd.ge = ws + c->ly[i + 1].dx; hd.a = ws + l.a; hd.s = ws + l.s;
+                    }
                     if (fin_in_gz)
                         WUNET_LAUNCH(gz_split_h3_kernel<true>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
                                      (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),

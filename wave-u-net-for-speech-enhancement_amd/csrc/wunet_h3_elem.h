@@ -262,7 +262,13 @@ static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(W
 // HEAD (the last decoder layer, whose only consumer is the 1x1 head): its g = wh[c] * gh * LeakyReLU'(a z + s) is a function of the
 // one-channel head gradient gh [B][L] (pass_a_kernel<A_HEAD>'s arithmetic, bit for bit) - recomputed here from gh (1 / C of the
 // bytes) instead of written by pass A and read back: the largest layer's g (100 MB at batch 64) never exists.
-struct GzHeadArgs { const float* gh; const float* wh; const float* a; const float* s; };
+// ENC (an encoder layer whose data gradients are whole tensors): its g = (dXdec[b, coff+c, l] + (l even ? dXenc[b, c, l/2] : 0)) * LeakyReLU'
+// (pass_a_kernel<A_ENC>'s arithmetic, bit for bit) is recomputed here from the two data gradients (6 bytes per value read instead of
+// the 4 of g) so that pass A does not WRITE g (4 bytes per value; a written byte costs 1.4 x a read one on this part).
+struct GzHeadArgs {
+    const float* gh; const float* wh; const float* a; const float* s;      // HEAD (gh != nullptr); a, s also ENC
+    const float* gd; const float* ge; int Cg0, coff;                        // ENC (gd != nullptr): dXdec [B][Cg0][L], dXenc [B][C][L/2]
+};
 #define WUNET_GZ_FIN_LOADS 1536   // (sweep 1152 / 2048 / 3100 / all: 5.41 / 5.42 / 5.46 / 5.50 ms per step - beyond the 512-sample level the prologue costs more than the launch)
 #define WUNET_GZ_FIN_C 512
 template <bool FIN>
@@ -360,6 +366,14 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                         if (!(ha * zv[j] + hs > 0.0f)) t *= WUNET_SLOPE;
                         gv[j] = t;
                     }
+                } else if (H.gd) {
+                    const wunet_f4 d4 = wunet_ld4(H.gd + ((size_t)b * H.Cg0 + H.coff + cc) * L + 4 * l4);
+                    const float2 e2 = *reinterpret_cast<const float2*>(H.ge + ((size_t)b * C + cc) * (L >> 1) + 2 * l4);
+                    const float ha = H.a[cc], hs = H.s[cc];
+                    gv[0] = d4[0] + e2.x; gv[1] = d4[1]; gv[2] = d4[2] + e2.y; gv[3] = d4[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(ha * zv[j] + hs > 0.0f)) gv[j] *= WUNET_SLOPE;
                 } else gv = wunet_ld4(g + o);
                 const float a = FIN ? ks[cc] : k1[cc], bb = FIN ? ks[WUNET_GZ_FIN_C + cc] : k2[cc], d = FIN ? ks[2 * WUNET_GZ_FIN_C + cc] : k3[cc];
 #pragma unroll
