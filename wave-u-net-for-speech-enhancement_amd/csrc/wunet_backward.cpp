@@ -74,7 +74,11 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         PassAArgs p{};
         p.z = ws + l.z; p.a = ws + l.a; p.s = ws + l.s; p.mean = ws + l.mean; p.rstd = ws + l.rstd;
         p.gpre = ws + l.g; p.part = ws + c->bpart_off; p.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; p.B = c->B; p.C = l.cout; p.L = l.L; p.logL = l.logL; p.Lt = l.Lt;
-        const dim3 ga(l.cout, l.a_split);
+        // grid (pieces, channels): consecutive blocks walk consecutive pieces of ONE channel row (rounds 1 - 3 had (channels, pieces):
+        // neighbours 4 L bytes apart; 5.156 -> 5.139 ms per step; WUNET_PA_SWAP=0: A/B switch)
+        static const int pa_swap = getenv("WUNET_PA_SWAP") ? atoi(getenv("WUNET_PA_SWAP")) : 1;
+        p.swap = (pa_swap && l.a_split > 1) ? 1 : 0;
+        const dim3 ga(p.swap ? l.a_split : l.cout, p.swap ? l.cout : l.a_split);
         const bool tiny = l.L < 4;
         // the first layer's g_z has one reader: its weight gradient forms it while it stages its chunks (WUNET_NO_GZ_FUSE: A/B switch)
         const bool gz_in_wgrad = i == 0 && !tiny && !l.h3d && !l.h3w && l.w.wsplit &&

@@ -416,6 +416,7 @@ struct PassAArgs {
     int coff;            // ENC: channel offset of the skip part inside dXdec
     int B, C, L, logL;
     float up_scale;      // UP: (float)(Lt-1)/(2Lt-1)
+    int swap;            // grid = (splits, C) instead of (C, splits)
     int Lt;              // samples of a row that exist (<= L, the power-of-two row stride; PrepArgs::Lt): the padding gets no gradient
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
@@ -426,11 +427,13 @@ template <int MODE, bool FUSE = false>
 __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
 {
     __shared__ double red[2 * WUNET_THREADS];
-    const int c = blockIdx.x;
+    // grid (C, splits), or (splits, C) with A.swap: consecutive blocks then walk consecutive pieces of ONE channel row
+    const int c = A.swap ? blockIdx.y : blockIdx.x;
+    const unsigned by = A.swap ? blockIdx.x : blockIdx.y, ny = A.swap ? gridDim.x : gridDim.y;
     // each thread produces four consecutive samples (aligned float4 traffic); L is a power of two >= 4
     const size_t total4 = ((size_t)A.B * A.L) >> 2;
-    const size_t per = (total4 + gridDim.y - 1) / gridDim.y;
-    const size_t beg = (size_t)blockIdx.y * per, end = beg + per < total4 ? beg + per : total4;
+    const size_t per = (total4 + ny - 1) / ny;
+    const size_t beg = (size_t)by * per, end = beg + per < total4 ? beg + per : total4;
     const float a = A.a[c], s = A.s[c], mu = A.mean[c], rstd = A.rstd[c];
     const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -566,14 +569,14 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         return;
     }
     if (threadIdx.x == 0) {
-        float* pr = A.part + ((size_t)blockIdx.y * A.C + c) * 2;
+        float* pr = A.part + ((size_t)by * A.C + c) * 2;
         pr[0] = (float)s1;
         pr[1] = (float)s2;
     }
     if (A.pmax) {
         block_max2(mg, mz, red);
         if (threadIdx.x == 0) {
-            float* pm = A.pmax + ((size_t)blockIdx.y * A.C + c) * 2;
+            float* pm = A.pmax + ((size_t)by * A.C + c) * 2;
             pm[0] = mg;
             pm[1] = mz;
         }
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         double dummy = 0.0;
         __syncthreads();
         block_sum2(s3, dummy, red);
-        if (threadIdx.x == 0) A.hpart[(size_t)blockIdx.y * A.C + c] = (float)s3;
+        if (threadIdx.x == 0) A.hpart[(size_t)by * A.C + c] = (float)s3;
     }
 }
 
