@@ -443,7 +443,8 @@ void layout_workspace(wunet_ctx* c)
         // pieces of a channel's B*L positions, one block of the gradient-assembly pass each: at least 4096 positions, at most 128 pieces
         // (round 4, with the blocks of one channel adjacent in the grid: 32 / 64 / 128 / 256 pieces -> 5.174 / 5.136 / 5.116 / 5.130 ms
         // per step; WUNET_A_CAP: measurement hook)
-        static const int a_cap = getenv("WUNET_A_CAP") ? atoi(getenv("WUNET_A_CAP")) : 128;
+        static const int a_cap_env = getenv("WUNET_A_CAP") ? atoi(getenv("WUNET_A_CAP")) : 128;
+        const int a_cap = a_cap_env < 1 ? 1 : (a_cap_env > 256 ? 256 : a_cap_env);      // (hpart2 below holds 256 rows)
         l.a_split = (int)(sp < 1 ? 1 : (sp > a_cap ? a_cap : sp));
         if ((size_t)l.a_split * l.cout * 2 > bpart_max) bpart_max = (size_t)l.a_split * l.cout * 2;
     }
