@@ -27,7 +27,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3w8_kernel(ConvH3A
     constexpr int NPL = BF ? 1 : 2;
     constexpr int XP = NPL * 4 * COLS;            // 16-byte pieces of the x tile
     constexpr int WPM = TG * 64;
-    constexpr int WP = NPL * M_REP * WPM;         // pieces of the W sub-tile of a stage
+    constexpr int WP = NPL * M_REP * WPM;         // pieces of one row group's W image of a stage
     static_assert(XP % 64 == 0 && WP % 64 == 0, "whole DMA instructions per wave");
     WUNET_DYN_SMEM(smem);
     wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS, de-interleaved][8]
@@ -40,8 +40,8 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3w8_kernel(ConvH3A
 
     // ---- per-thread source descriptors of its DMA pieces (independent of the work item).  A DMA instruction of a wave writes one
     // RUN of 64 consecutive pieces; the runs of the x image ([plane][4 groups][COLS, de-interleaved]: RP runs per plane) are dealt
-    // so that the plane of an instruction is a compile-time constant: instruction it < NPL*XF covers runs 4 (it % XF) + wave of
-    // plane it / XF, the XR left-over runs of every plane share one last instruction (wave -> plane wave / XR, run 4 XF + wave % XR).
+    // so that the plane of an instruction is a compile-time constant: instruction it < NPL*XF covers runs NW (it % XF) + wave of
+    // plane it / XF, the XR left-over runs of every plane share one last instruction (wave -> plane wave / XR, run NW XF + wave % XR).
     // Piece p of a plane is (channel group c8 = p / COLS, column col = 4 (w % Q4) + w / Q4 with w = p % COLS - the de-interleave).
     // Kept per piece: xoffb = bytes from 8 samples in front of the tile's first sample in the chunk's first channel group of the hi
     // plane (never negative: the DMA takes an SGPR base + an unsigned 32-bit offset per lane; the lo plane lies A.xdelta bytes behind
@@ -229,8 +229,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3w8_kernel(ConvH3A
             else acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);                          \
         }
             // After the B fragments: the x tile is free once every wave holds them; the prefetch of the next step's A fragments is
-            // ISSUED at the fence, not sunk to its first use; with the last A fragments of the stage in flight the W sub-tile is free
-            // once every wave has them.  A tail stage runs the first NTT steps only.
+            // ISSUED at the fence, not sunk to its first use.  A tail stage runs the first NTT steps only.
             WUNET_H3D_LOAD_F(true)
             WUNET_H3D_LOAD_A(0, 0)
             if (x_next) {
@@ -247,8 +246,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3w8_kernel(ConvH3A
         if (tl & 1) { WUNET_H3D_PASS(0, 1, tl) } else { WUNET_H3D_PASS(0, 0, tl) }                                \
         if (tl & 1) { WUNET_H3D_PASS(1, 1, tl) WUNET_H3D_PASS(2, 1, tl) } else { WUNET_H3D_PASS(1, 0, tl) WUNET_H3D_PASS(2, 0, tl) } \
     }
-            // (the steps a tail stage skips behind ONE uniform branch; TG - 2 >= NTT, 5 taps: the W sub-tile of a full stage is
-            // released inside them, that of a tail stage at its step NTT - 2)
+            // (the steps a tail stage skips behind ONE uniform branch)
             static_assert(TG == 5 && (NTT == 4 || NTT == 2), "step list below");
             if (act) {                            // (a group without rows: no MFMAs beside the other group's, only the barriers and its x pieces)
                 WUNET_H3D_STEP(0) WUNET_H3D_STEP(1)
