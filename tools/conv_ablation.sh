@@ -5,6 +5,7 @@
 #   bits: 1 no MFMAs   2 no DMA at all   4 no output stores   8 no x-tile DMA   16 no W DMA   32 no vmcnt wait at the top of a stage
 #         128 every x piece from the 16-byte zero pad (cache hit)   256 every W run from the first run of the pack (cache hit)
 #         512 two MFMA passes instead of three (the W_lo x_hi products dropped: what a pass costs)
+#         1024 the x tile's DMA without the de-interleave (every instruction 1 KiB contiguous, wrong columns, same bytes): what the gather costs
 #   tools/conv_ablation.sh build      (container: hipcc)  ->  tools/_lib_abl<bits>.so  (git-ignored, shipped by gpurun)
 #   tools/conv_ablation.sh run        (GPU box)           ->  gpurun_out/conv_ablation.txt
 set -e

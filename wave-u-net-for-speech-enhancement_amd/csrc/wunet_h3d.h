@@ -76,7 +76,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         bool live = true;
         if (it == NPL * XF) { pl = wave / (XR ? XR : 1); run = 4 * XF + wave % (XR ? XR : 1); live = wave < XR * NPL; xrun = run; }
         const int p = run * 64 + lane, c8 = p / COLS, w = p % COLS;
-        const int col = 4 * (w % Q4) + w / Q4, seg = col / SW, lrel = col - seg * SW - 8;
+        const int col = (WUNET_ABL & 1024) ? w : 4 * (w % Q4) + w / Q4, seg = col / SW, lrel = col - seg * SW - 8;      // (ablation 1024: no de-interleave - every DMA instruction 1 KiB contiguous, wrong columns)
         xoffb[it] = ((seg * A.C8 + c8) * L + lrel + 8) * 16 + (NPL > 1 && (pl & 1) ? (int)A.xdelta : 0);
         m_live |= (unsigned)live << it;
         m_lo |= (unsigned)(lrel < 0) << it;
