@@ -54,8 +54,37 @@ def net_flops_bytes(n, ci, frame):
     return fl, by
 
 
+def _code_only(text):
+    """C / C++ source with comments removed and white space collapsed: what the compiler sees, up to spelling.  (String and character
+    literals are walked so that a // or /* inside one is kept.)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c == "/" and i + 1 < n and text[i + 1] == "/":
+            while i < n and text[i] != "\n":
+                if text[i] == "\\" and i + 1 < n:          # a line comment continued by a backslash
+                    i += 1
+                i += 1
+        elif c == "/" and i + 1 < n and text[i + 1] == "*":
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        elif c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash():
-    """sha1 over the kernel + host sources: measurements stored under profiles/ are stamped with it and refused when stale."""
+    """sha1 over the CODE of the kernel + host sources (comments and white space do not count: a comment edit after the PMC pass must
+    not void the round's traffic figures - VERDICT r4 #10): measurements stored under profiles/ are stamped with it and refused when
+    stale."""
     import glob
     import hashlib
     h = hashlib.sha1()
@@ -63,7 +92,7 @@ def source_hash():
                    glob.glob(os.path.join(ROOT, "include", "*.h")))
     for f in files:
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(_code_only(open(f, "r", errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
@@ -172,7 +201,7 @@ def roofline_of(rows, nprof, pmc, step_algorithmic_bytes):
             "kernels_timed_per_step": sum(r["launches"] for r in rows) / nprof}
 
 
-def timed(fn, warmup, steps, batch, what):
+def timed(fn, warmup, steps, batch, what, median_steps=0):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
@@ -181,7 +210,18 @@ def timed(fn, warmup, steps, batch, what):
         fn()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    return {"what": what, "ms_per_step": dt * 1e3, "frames_per_s": batch / dt, "steps": steps}
+    r = {"what": what, "ms_per_step": dt * 1e3, "frames_per_s": batch / dt, "steps": steps, "warmup": warmup}
+    if median_steps:
+        # the same call timed step by step with device events: median and quartiles say whether the window above was disturbed
+        per = []
+        for _ in range(median_steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); e1.synchronize()
+            per.append(e0.elapsed_time(e1))
+        per.sort()
+        r.update(ms_per_step_median=per[len(per) // 2], ms_per_step_p25=per[len(per) // 4], ms_per_step_p75=per[(3 * len(per)) // 4],
+                 frames_per_s_at_median=batch / per[len(per) // 2] * 1e3)
+    return r
 
 
 def synthetic_batch(batch, device, seed, frame=FRAME):
@@ -298,18 +338,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    # TEST HOOK, never a measurement: WUNET_BENCH_EMU=1 (tests/test_bench_contract.py) runs this file's multi-rank branches in the
+    # GPU-less container - gloo, CPU tensors, the kernels on tests/emu's fiber emulator - so that `torchrun ... bench.py --gpus N`
+    # stays correct by construction while no multi-GPU node is at hand.  The line it prints says so in `data`.
+    emu = bool(os.environ.get("WUNET_BENCH_EMU"))
+    if not emu and not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+    device = torch.device("cpu") if emu else torch.device("cuda", local_rank)
+    dsync = (lambda: None) if emu else torch.cuda.synchronize
+    if not emu:
+        torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     pkg = importlib.import_module(PKG)
     parallel = importlib.import_module(PKG + ".parallel")
     engine_mod = importlib.import_module(PKG + ".engine")
+    emu_engine = None
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_lib
+        emu_engine = engine_mod.Engine(lib=importlib.import_module(PKG + "._lib").declare(emu_lib.lib()), host_memory=True)
+        args.no_roofline = args.no_extras = args.no_cpu_baseline = True
 
     torch.manual_seed(args.seed)                 # same init on every rank (reference train.py:12)
     model = pkg.Model(n_layers=args.layers, channels_interval=CI).to(device).train()
@@ -317,6 +372,10 @@ def main():
     optim_mod = importlib.import_module(PKG + ".optim")
     adam_cls = torch.optim.Adam if args.torch_adam else optim_mod.FusedAdam     # reference train.py:31-35
     opt = adam_cls(model.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    if emu_engine is not None:
+        model._engine_override = crit._engine_override = emu_engine
+        if not args.torch_adam:
+            opt._engine_override = emu_engine
     if world > 1 or args.native_rccl:
         # bucketed RCCL all-reduce inside the backward; the 1/world of the average is folded into the fused Adam step
         # (same rounding, four launches and 2 x 40 MB of traffic less per step) unless torch's optimiser is used
@@ -345,7 +404,7 @@ def main():
         return loss
 
     fused_adam = not args.torch_adam
-    use_graph = args.mode == "train" and fused_adam and (
+    use_graph = not emu and args.mode == "train" and fused_adam and (
         (args.graph == "on" and (world == 1 or args.native_rccl)) or (args.graph == "auto" and world == 1))
     eager_step = step
     if use_graph:
@@ -355,7 +414,7 @@ def main():
     if use_graph:
         # the same work as `step`, captured once: every kernel of forward, loss, backward (both streams) and the Adam step
         try:
-            torch.cuda.synchronize()
+            dsync()
             opt.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -377,15 +436,15 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
             use_graph = False
             step = eager_step
-            torch.cuda.synchronize()
+            dsync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    dsync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     enqueue = time.perf_counter() - t0          # host time to issue the K steps (the GPU runs behind it)
-    torch.cuda.synchronize()
+    dsync()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -397,7 +456,7 @@ def main():
     # a second pass of the same K steps timed one by one with device events: the median is robust against a clock ramp or a
     # hiccup inside the short timed region above (which stays the headline, as the contract defines it)
     step_ms = []
-    for _ in range(0 if os.environ.get("WUNET_BENCH_NO_MEDIAN") else args.steps):      # (switch: the PMC passes count launches per step)
+    for _ in range(0 if (os.environ.get("WUNET_BENCH_NO_MEDIAN") or emu) else args.steps):      # (switch: the PMC passes count launches per step)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         step()
@@ -416,9 +475,9 @@ def main():
     sync = getattr(model, "grad_sync", None)
     if sync is not None and args.mode == "train":
         sync.measure = True
-        for _ in range(5):
+        for _ in range(1 if emu else 5):
             eager_step()
-        torch.cuda.synchronize()
+        dsync()
         sync.measure = False
         ex = sync.exposed_ms()
         mine = torch.tensor([sum(ex) / max(len(ex), 1)], device=device, dtype=torch.float64)
@@ -452,11 +511,11 @@ def main():
         extras = {}
         # the contract's K = 20 steps are a 0.1 s window; 200 back-to-back steps and the median of 200 event-timed steps of the SAME step
         # function resolve a 1 - 2 % change (the boxes of the pool differ by more than that: compare within one run)
-        torch.cuda.synchronize()
+        dsync()
         t_l = time.perf_counter()
         for _ in range(200):
             step()
-        torch.cuda.synchronize()
+        dsync()
         long_ms = (time.perf_counter() - t_l) / 200 * 1e3
         per = []
         for _ in range(200):
@@ -473,7 +532,8 @@ def main():
         def fwd():
             with torch.no_grad():
                 model(noisy)
-        extras["eval_forward"] = timed(fwd, 10, 20, args.batch, "eval-mode forward only (BASELINE configs[1], enhancement.py path), default GEMM arithmetic")
+        extras["eval_forward"] = timed(fwd, 10, 50, args.batch, "eval-mode forward only (BASELINE configs[1], enhancement.py path), default GEMM arithmetic",
+                                       median_steps=50)
         if not args.no_roofline:
             # BASELINE configs[1] carries its own roofline: the dominant GEMM kernel of the eval forward (HIP events of the same calls)
             # and the PMC traffic of its own passes (tools/measure_round.sh: `bench.py --mode forward` under --pmc)
@@ -515,9 +575,9 @@ def main():
                 o16.zero_grad(set_to_none=True)
                 c16(cl16, m16(n16)).backward()
                 o16.step()
-            d16 = timed(step16, 3, 10, 32, "training step of the 16-level / 65536-sample net at batch 32, bf16 GEMM operands (WUNET_H3=3): BASELINE.json "
+            d16 = timed(step16, 10, 50, 32, "training step of the 16-level / 65536-sample net at batch 32, bf16 GEMM operands (WUNET_H3=3): BASELINE.json "
                                             "configs[4] (24 levels do not exist at 65536 samples, SURVEY.md section 0); outside the 1e-4 fp32 parity bar, "
-                                            "checked against the reference under bf16 autocast (tests/test_gpu_parity.py)")
+                                            "checked against the reference under bf16 autocast (tests/test_gpu_parity.py)", median_steps=50)
             d16["value"], d16["unit"] = d16["frames_per_s"], "65536-sample frames/s"
             d16["dtype"] = "bf16 operands, f32 accumulate / BatchNorm / gradients"
             f16fl, f16by = net_flops_bytes(16, CI, 65536)
@@ -549,7 +609,7 @@ def main():
             "dtype": ("bf16 operands, f32 accumulate / BatchNorm / gradients (levels >= 16 samples: 1 x bf16 MFMA; the rest f32 MFMA)" if bf16_gemm
                       else "f32 (levels >= 16 samples: 3 x f16 MFMA on hi/lo fp16 halves, fp32 accumulate; the rest f32 MFMA)" if split_gemm
                       else "f32"),
-            "data": "synthetic",
+            "data": "synthetic" if not emu else "synthetic; CPU EMULATOR RUN (WUNET_BENCH_EMU test hook) - NOT A MEASUREMENT",
             "config": {"workload": f"unet_basic {args.layers}-level, {args.frame}-sample frames, batch={args.batch} per GPU, fp32, "
                                    "training-mode forward + smooth_l1 + backward + " + ("torch.optim.Adam" if args.torch_adam else "fused HIP Adam") + " step "
                                    "(BASELINE.json configs[2]; configs[3] when n_gpus>1)",

@@ -65,3 +65,50 @@ def test_traffic_table_runs_over_the_committed_profiles(tmp_path):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "traffic_table.py"), os.path.join(ROOT, "profiles", "r3_bench.json")],
                          capture_output=True, text=True, check=True).stdout
     assert "conv_h3d_kernel" in out and "pass_a_kernel" in out and "all kernels" in out
+
+
+def test_source_hash_ignores_comments_and_white_space():
+    """VERDICT r4 #10: a comment edit after the PMC pass must not void the round's traffic figures; a code edit must."""
+    a = "int f(int x) { return x + 1; }   // plus one\n/* block\n   comment */ const char* s = \"// kept /* kept\";\n"
+    b = "int f(int x)\n{\n    return x + 1;\n}\nconst char* s = \"// kept /* kept\";   // another remark\n"
+    assert bench._code_only(a) == bench._code_only(b).replace("( int", "(int")
+    assert bench._code_only(a) != bench._code_only(a.replace("x + 1", "x + 2"))
+    assert bench._code_only(a) != bench._code_only(a.replace("// kept", "// dropped"))          # string literals are code
+    assert "plus one" not in bench._code_only(a) and "comment" not in bench._code_only(a).replace("a comment", "")
+
+
+def test_bench_world2_branches_run_on_gloo_and_the_emulator(tmp_path):
+    """VERDICT r4 #9: `torchrun --nproc-per-node N bench.py --gpus N` green by construction without a multi-GPU node - the world > 1
+    branches of bench.py (process group, GradSync attach, 1/world in the Adam step, max-over-ranks timing, the gradient_exchange
+    record, matched profiled passes) driven at world 2 over gloo with the kernels on the CPU emulator (WUNET_BENCH_EMU test hook)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, WUNET_BENCH_EMU="1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--layers", "3", "--frame", "256", "--batch", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                         # rank 0 prints ONE line
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["scaling"] == "weak" and j["config"]["global_batch"] == 4
+    assert "NOT A MEASUREMENT" in j["data"] and j["roofline"] is None and j["cpu_baseline"] is None
+    ex = j["gradient_exchange"]
+    assert ex["world"] == 2 and ex["transport"].startswith("torch.distributed gloo") and ex["scale"] == "1/world in the Adam step"
+    assert len(ex["bucket_bytes"]) == 4 and len(ex["allreduce_exposed_ms_per_rank"]) == 2
+    import importlib
+    from conftest import PKG_NAME
+    plan = importlib.import_module(PKG_NAME + ".plan")
+    numel = sum(co * ci_ * k + 3 * co for ci_, co, k in plan.conv_layer_shapes(3, 24)) + 24 + 1 + 1
+    assert sum(ex["bucket_bytes"]) == 4 * numel
+    assert j["value"] > 0 and j["final_loss"] == j["final_loss"]
+    # the headline shape's buckets (host logic only): four buckets, 40.53 MB together
+    parallel = importlib.import_module(PKG_NAME + ".parallel")
+    numels = []
+    for c_in, c_out, k in plan.conv_layer_shapes(12, 24):
+        numels += [c_out * c_in * k, c_out, c_out, c_out]
+    numels += [25, 1]
+    rs = parallel.bucket_ranges(numels, 25, 4)
+    assert len(rs) == 4 and abs(sum(4 * (fe - fb) for _, _, fb, fe in rs) / 1e6 - 40.53) < 0.01

@@ -77,3 +77,53 @@ def test_full_12_level_digest():
         ref = fx["buf_digest"][i]
         got = digest(sd[k])
         assert abs(got[0] - ref[0]) < 1e-4 * abs(ref[0]) + 1e-6, k
+
+
+# ---- the travelling port against the imported reference, every run in the build container (VERDICT r4 missing #5): the full-size GPU
+# tests and bench.py's cpu_baseline use oracle/torch_port.py, so its equality with /root/reference/model/unet_basic.py + model/loss.py
+# is checked here and not only when somebody regenerates the fixtures
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("n,ci,B,T,loss_kind", [(3, 4, 2, 64, "mse"), (5, 8, 3, 512, "l1"), (4, 6, 2, 256, "smooth_l1"), (12, 24, 2, 4096, "mse")])
+def test_torch_port_equals_the_imported_reference(monkeypatch, n, ci, B, T, loss_kind):
+    import sys
+    import torch
+    from oracle import torch_port
+    sys.dont_write_bytecode = True
+    monkeypatch.syspath_prepend(REF)
+    for name in [m for m in sys.modules if m.split(".")[0] == "model"]:
+        monkeypatch.delitem(sys.modules, name, raising=False)
+    try:
+        from model.unet_basic import Model as RefModel          # the reference, unmodified
+        from model import loss as ref_loss
+        sd_np = plan.golden_state(n, ci, seed=0)
+        noisy_np, clean_np = plan.golden_batch(B, T, seed=0)
+        noisy, clean = torch.from_numpy(noisy_np), torch.from_numpy(clean_np)
+        model = RefModel(n_layers=n, channels_interval=ci)
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd_np.items()})
+        crit = {"mse": ref_loss.mse_loss, "l1": ref_loss.l1_loss, "smooth_l1": torch.nn.SmoothL1Loss}[loss_kind]()
+        # eval path (enhancement.py:43,65-66)
+        model.eval()
+        with torch.no_grad():
+            ref_eval = model(noisy)
+            port_eval = torch_port.forward(torch_port.state_to_torch(sd_np), noisy, n, ci, False)
+        assert torch.equal(ref_eval, port_eval)
+        # training step (trainer/trainer.py:34-37): output, loss, every gradient, the running statistics
+        model.train()
+        loss = crit(clean, model(noisy))
+        loss.backward()
+        tsd = torch_port.state_to_torch(sd_np, requires_grad=True)
+        out = torch_port.forward(tsd, noisy, n, ci, True)
+        l2 = torch_port.loss_value(loss_kind, clean, out)
+        l2.backward()
+        assert loss.item() == l2.item()
+        for k, p in model.named_parameters():
+            assert torch.equal(p.grad, tsd[k].grad), k
+        post = model.state_dict()
+        for k in plan.buffer_names(n, ci):
+            assert torch.equal(post[k], tsd[k]), k
+    finally:
+        for name in [m for m in sys.modules if m.split(".")[0] == "model"]:
+            sys.modules.pop(name, None)

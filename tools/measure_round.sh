@@ -6,6 +6,11 @@
 # one-stream).  tools/collect_round.py <tag> then copies the summaries into profiles/ and rebuilds profiles/pmc_traffic.json
 # (stamped with the source hash) here.
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/final; rm -rf $O; mkdir -p $O
+# only from a clean tree: tools/run_measure_round.sh (build container) refuses a dirty csrc/ and leaves the commit + source hash here
+if [ ! -f $R/tools/_git_state ] || [ "$(cut -d' ' -f3 $R/tools/_git_state)" != "$(cd $R && python -c 'import bench; print(bench.source_hash())')" ]; then
+    echo "refused: tools/_git_state missing or not these sources - start the measurement with tools/run_measure_round.sh" >&2; exit 2
+fi
+cp $R/tools/_git_state $O/git_state.txt
 TAG=${TAG:-r4}
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json

@@ -1,6 +1,5 @@
 // Instantiation unit: conv_h3d_kernel<TAPS, M_REP, NSEG, BF> (fp16-split conv / data gradient, DMA-staged and pipelined).
 #include "wunet_h3d.h"
-#include "wunet_h3d8.h"
 #include "wunet_launch.h"
 
 #define WUNET_XCASE(T, M, S)                                                                               \
@@ -27,15 +26,3 @@ int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim
     return -1;
 }
 
-// conv_h3w8_kernel<TAPS, M_REP>: the eight-wave form (one block per CU, two row groups over one x tile); un-segmented levels, two planes
-#define WUNET_X8CASE(T, M)                                                                                 \
-    if (taps == T && mrep == M) {                                                                          \
-        if (WUNET_ALLOW_BIG_LDS((conv_h3w8_kernel<T, M>), smem) != 0) return -2;                           \
-        WUNET_LAUNCH((conv_h3w8_kernel<T, M>), grid, dim3(2 * WUNET_THREADS), smem, st, a);                \
-        return 0;                                                                                          \
-    }
-int wunet_launch_conv_h3w8(const ConvH3Args& a, int taps, int mrep, dim3 grid, size_t smem, hipStream_t st)
-{
-    WUNET_X8CASE(15, 2) WUNET_X8CASE(15, 3) WUNET_X8CASE(5, 2) WUNET_X8CASE(5, 3)
-    return -1;
-}

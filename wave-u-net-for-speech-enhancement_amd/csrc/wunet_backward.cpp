@@ -77,9 +77,9 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         // grid (pieces, channels): consecutive blocks walk consecutive pieces of ONE channel row (rounds 1 - 3 had (channels, pieces):
         // neighbours 4 L bytes apart; 5.156 -> 5.139 ms per step; WUNET_PA_SWAP=0: A/B switch)
         static const int pa_swap = getenv("WUNET_PA_SWAP") ? atoi(getenv("WUNET_PA_SWAP")) : 1;
-        p.swap = (pa_swap && l.a_split > 1) ? 1 : 0;
-        const dim3 ga(p.swap ? l.a_split : l.cout, p.swap ? l.cout : l.a_split);
         const bool tiny = l.L < 4;
+        p.swap = (pa_swap && l.a_split > 1 && !tiny) ? 1 : 0;        // (pass_a_scalar_kernel reads its channel from blockIdx.x)
+        const dim3 ga(p.swap ? l.a_split : l.cout, p.swap ? l.cout : l.a_split);
         // the first layer's g_z has one reader: its weight gradient forms it while it stages its chunks (WUNET_NO_GZ_FUSE: A/B switch)
         const bool gz_in_wgrad = i == 0 && !tiny && !l.h3d && !l.h3w && l.w.wsplit &&
                                  !(l.a_split == 1 && (size_t)c->B * l.L <= 4 * WUNET_THREADS);       // (not where pass A finishes g_z itself)
@@ -226,9 +226,11 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     ra.Cout = l.cout; ra.Cin = l.cin; ra.taps = l.taps; ra.mrep = l.h3w_mrep; ra.tw = l.taps == 15 ? 8 : 5;
                     ra.nblocks = l.h3w_nblocks; ra.mblocks = l.h3w_mblocks; ra.cib = l.taps == 15 ? 32 : 64;
                     // few splits over many outputs: the barrier-free serial form (64, 8192: 6.19 -> 6.13 ms per step in round 1).
-                    // Test hook WUNET_REDUCE_SERIAL = "<max splits>,<min float4 outputs>": tiny shapes reach that kernel
+                    // Emulator-build test hook WUNET_REDUCE_SERIAL = "<max splits>,<min float4 outputs>": tiny shapes reach that kernel
                     int serial_max = 64; long long serial_min_n4 = 8192;
+#ifdef WUNET_EMU
                     if (const char* e = getenv("WUNET_REDUCE_SERIAL")) sscanf(e, "%d,%lld", &serial_max, &serial_min_n4);
+#endif
                     const size_t n4 = ra.part_stride / 4;
                     if (ra.splits <= serial_max && (long long)n4 >= serial_min_n4) {
                         size_t blocks = (n4 + WUNET_THREADS - 1) / WUNET_THREADS;

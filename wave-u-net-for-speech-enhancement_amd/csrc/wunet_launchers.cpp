@@ -89,12 +89,12 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
     WUNET_LAUNCH(split_act_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, x, hi, lo, sc, xb0, xb1, xsc, B, C, c8, L, ilog2(L), bf);
     return 0;
 }
-// resident conv_h3d blocks the grid is sized for: two per CU (its launch bounds); WUNET_H3_GRID overrides (tests: a few blocks walk
-// many work items)
+// resident conv_h3d blocks the grid is sized for: two per CU (its launch bounds).  Emulator build only: WUNET_H3_GRID overrides
+// (tests: a few blocks walk many work items) - the product reads no environment on a launch path
 int h3_grid_cap()
 {
-    if (const char* e = getenv("WUNET_H3_GRID")) { const int v = atoi(e); if (v > 0) return v; }
 #ifdef WUNET_EMU
+    if (const char* e = getenv("WUNET_H3_GRID")) { const int v = atoi(e); if (v > 0) return v; }
     return 1 << 30;
 #else
     static int cus[64];
@@ -132,25 +132,6 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     a.trace = g_h3_trace;
-    // WUNET_H3_RG=2 (experiment): the eight-wave kernel - one block per CU, two row groups over one x tile, the W image
-    // double-buffered - on the un-split, un-segmented two-plane layers; 4 accumulator rows per wave run as pairs of 2
-    const int rg_env = getenv("WUNET_H3_RG") ? atoi(getenv("WUNET_H3_RG")) : 1;      // (read per launch: tools/conv_bench.py switches it between runs)
-    if (rg_env == 2 && nseg == 1 && !bf && ksplit == 1 && a.mblocks * mrep >= 2) {
-        const int m8 = mrep == 4 ? 2 : mrep;
-        a.mblocks = mtiles_p / m8;
-        const size_t smem8 = (size_t)(2 * 4 * 272 + 4 * 2 * m8 * 5 * 64) * 16 + (size_t)(8 * m8 * 32 + 8) * sizeof(float);
-        const int items8 = a.ntiles * ((a.mblocks + 1) / 2);
-        int g8 = h3_grid_cap() / 2;
-        if (g8 < items8) g8 &= ~7;
-        if (g8 > items8) g8 = items8;
-        snprintf(pname, sizeof pname, "conv_h3w8_kernel<%d, %d>", taps, m8);
-        prof_begin(st, pname, 2.0 * posn * rows * kch * taps, 4.0 * posn * (rows + kch));
-        if (getenv("WUNET_H3_RG_VERBOSE")) fprintf(stderr, "conv_h3w8_kernel<%d, %d> grid %d items %d smem %zu\n", taps, m8, g8, items8, smem8);
-        const int rc8 = wunet_launch_conv_h3w8(a, taps, m8, dim3((unsigned)g8, 1), smem8, st);
-        prof_end(st);
-        if (rc8 != 0) return fail(WUNET_E_ARG, "no conv_h3w8 kernel for taps=%d mrep=%d (rc %d)", taps, m8, rc8);
-        return 0;
-    }
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
     snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)));

@@ -5,6 +5,7 @@ import collections
 import ctypes
 import os
 import threading
+import weakref
 
 import torch
 
@@ -28,6 +29,24 @@ def bump_versions(tensors):
     except TypeError:                    # torch 2.1 - 2.4: one tensor per call
         for t in tensors:
             inc(t)
+
+
+class _ParamSignature:
+    """What the eval-mode weight-pack cache is valid for: THESE parameter tensor objects (weak references - an address the caching
+    allocator hands to the next model's weights is not the same tensor), at these addresses and autograd versions, and no device-side
+    rewrite (Engine.weights_generation) since."""
+    __slots__ = ("refs", "state", "gen")
+
+    def __init__(self, params, gen):
+        self.refs = [weakref.ref(p) for p in params]
+        self.state = tuple((p.data_ptr(), p._version) for p in params)
+        self.gen = gen
+
+    def matches(self, other):
+        """self: the cached entry; other: the signature of the call's parameters (alive by construction)."""
+        if self.gen != other.gen or self.state != other.state or len(self.refs) != len(other.refs):
+            return False
+        return all(a() is b() and a() is not None for a, b in zip(self.refs, other.refs))
 
 
 class FlatGrads:
@@ -79,6 +98,9 @@ class Engine:
         self._ctx = collections.OrderedDict()
         self._lock = threading.Lock()
         self._eval_ws = collections.OrderedDict()     # (shape, device, stream) -> (workspace of the last eval forward, parameter signature)
+        # Bumped by everything that rewrites weights WITHOUT moving a Python version counter: the replay of a captured step graph
+        # (FusedAdam.advance_host_step) - part of the eval cache's signature, so an eval forward after N replays re-packs.
+        self.weights_generation = 0
         # per-step calls marshalled in C++ when the extension is built and this engine drives the HIP library it is linked to
         self._fast = _load_torch_ext() if (lib is None and not host_memory) else None
 
@@ -168,13 +190,20 @@ class Engine:
         # on this (shape, device, stream) is used again, and while no parameter has changed - addresses and autograd version counters,
         # which every in-place torch op, load_state_dict and FusedAdam.step move - the weight packs in it are not rebuilt
         cache = sig = None
-        if not training and not with_backward and not self.host_memory and not os.environ.get("WUNET_NO_EVAL_CACHE"):      # (switch: A/B)
+        if training and self._eval_ws:
+            self.drop_eval_cache()           # training resumes: the eval workspaces (up to MAX_EVAL_WORKSPACES whole forwards) go back to the allocator
+        if (not training and not with_backward and not self.host_memory and noisy.is_cuda and noisy.dtype == torch.float32
+                and not os.environ.get("WUNET_NO_EVAL_CACHE")):                       # (switch: A/B; a CPU / non-float input falls through to _require's error)
             key = (n_layers, ci, noisy.shape[0], noisy.shape[2], str(noisy.device), torch.cuda.current_stream(noisy.device).cuda_stream)
-            sig = tuple((p.data_ptr(), p._version) for p in params)
-            with self._lock:
-                cache = self._eval_ws.pop(key, None)             # (popped: a second thread on the same key takes a fresh workspace)
-            if cache is not None and cache[1] != sig:
-                cache = (cache[0], None)
+            try:
+                sig = _ParamSignature(params, self.weights_generation)
+            except (RuntimeError, TypeError):                                         # inference tensors have no version counter: no cache
+                sig = None
+            if sig is not None:
+                with self._lock:
+                    cache = self._eval_ws.pop(key, None)         # (popped: a second thread on the same key takes a fresh workspace)
+                if cache is not None and not cache[1].matches(sig):
+                    cache = (cache[0], None)
         if self._fast is not None:
             with self._using(n_layers, ci, noisy.shape[0], noisy.shape[2], noisy.device) as h:
                 try:
@@ -210,6 +239,11 @@ class Engine:
             self._eval_ws[key] = (ws, sig)
             while len(self._eval_ws) > self.MAX_EVAL_WORKSPACES:            # (variable-length inference: the oldest shapes go)
                 self._eval_ws.pop(next(iter(self._eval_ws)))
+
+    def note_weights_changed(self):
+        """Weights were rewritten on the device without a Python-side in-place op (a graph replay that contains the optimiser step):
+        cached eval weight packs of every model on this engine are stale from here on."""
+        self.weights_generation += 1
 
     def drop_eval_cache(self):
         """Forget the eval-mode workspaces (and with them the cached weight packs): for a caller that changed weights behind autograd's

@@ -76,6 +76,8 @@ class FusedAdam(torch.optim.Optimizer):
                     seen[id(st["step"])] = st["step"]           # (the parameters of a group share one counter object, see step())
         for t in seen.values():
             t += n
+        # the replay rewrote the weights on the device; no Python version counter moved (engine.py: the eval weight-pack cache)
+        self._engine().note_weights_changed()
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -29,8 +29,8 @@ from .optim import FusedAdam
 from .parallel import GradSync
 
 GRAPH_WARMUP_STEPS = 3
-MAX_RECAPTURES = 3           # hyper-parameter changes in a row (each closer than RECAPTURE_RESET replays to the last) before the graph is given up
-RECAPTURE_RESET = 50
+MAX_RECAPTURES = 3           # hyper-parameter changes in a row (each at most RECAPTURE_RESET replays after the last) before the graph is given up
+RECAPTURE_RESET = 2          # "in a row" = a PER-STEP schedule; a per-epoch scheduler, however short the epoch, keeps its graph
 
 
 class Trainer:
@@ -168,15 +168,16 @@ class Trainer:
             # lr / betas / eps / grad_scale are kernel arguments of the captured Adam step: a scheduler, a manual decay or a
             # load_state_dict with another lr would be ignored by the replay - capture again with the new values.  A schedule that
             # changes them EVERY step would turn each step into capture + instantiate + one replay (far slower than eager): after
-            # MAX_RECAPTURES changes with fewer than RECAPTURE_RESET replays in between, the graph is given up for eager launches.
+            # MAX_RECAPTURES changes with at most RECAPTURE_RESET replays in between, the graph is given up for eager launches.
             self._graph = None
-            self._recaptures = self._recaptures + 1 if self._replays < RECAPTURE_RESET else 1
+            self._recaptures = self._recaptures + 1 if self._replays <= RECAPTURE_RESET else 1
             self._replays = 0
             if self._recaptures > MAX_RECAPTURES:
                 import warnings
                 warnings.warn("Trainer: the optimiser's hyper-parameters change every few steps (a per-step LR schedule?); the captured "
                               "step graph would be rebuilt each time - falling back to eager launches", RuntimeWarning)
                 self.use_graph = False
+                self._fall_back_to_host_step()
                 return self._eager_step(mixture, clean)
         if self._graph is None:
             if self._eager_steps < GRAPH_WARMUP_STEPS:
@@ -192,6 +193,12 @@ class Trainer:
         self._replays += 1
         self.optimizer.advance_host_step(1)
         return self._static_loss
+
+    def _fall_back_to_host_step(self):
+        """Eager from here on: the optimiser counts its steps on the host again (its state["step"] has been kept in step with the
+        device counter by advance_host_step; the device counter is dropped and would be re-seeded if the graph ever came back)."""
+        self.optimizer.device_step = False
+        self.optimizer._dev = {}
 
     def _train_epoch(self, epoch):
         sampler = getattr(self.train_data_loader, "sampler", None)
