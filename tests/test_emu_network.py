@@ -264,3 +264,54 @@ def test_fused_adam_matches_torch(emu_engine):
     for k in sd_ref["state"]:
         assert set(sd_ref["state"][k].keys()) == set(sd_our["state"][k].keys())
         assert (sd_ref["state"][k]["exp_avg_sq"] - sd_our["state"][k]["exp_avg_sq"]).abs().max().item() < 1e-7
+
+
+@pytest.mark.parametrize("n,ci,B,T,grid", [(2, 24, 2, 1024, "8"),      # persistent blocks walk two items each; chunks with both branches
+                                           (3, 24, 1, 2048, "4"),      # three decoder levels on the kernel, 8 / 4 / 2 tiles per row
+                                           (2, 16, 3, 512, "")])       # 16-channel groups: one branch per chunk pair, a half-empty last chunk
+def test_fused_operand_conv_matches_the_two_kernel_path(monkeypatch, n, ci, B, T, grid):
+    """conv_h3u_kernel (wunet_h3u.h: the decoder conv whose loader waves build the operand from the producers' raw conv outputs - BatchNorm
+    scale / shift, LeakyReLU, ATen's upsample coordinates, concat, split - instead of reading what prep_h3_kernel wrote) against the oracle
+    and against prep_h3_kernel + conv_h3d_kernel, in eval mode (its product use) and in training mode (statistics rows, the operand written
+    out for the weight gradient).  WUNET_H3U = "<eval min L>,<train min L>" is read when a context is planned: every arm its own engine."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    pkg_loss = importlib.import_module(PKG_NAME + ".loss")
+    monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")
+    if grid:
+        monkeypatch.setenv("WUNET_H3_GRID", grid)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    sd = plan.golden_state(n, ci, 0)
+    ref_e = c_oracle.step(sd, noisy, clean, n, ci, False, "mse", want_grads=False, precision="f64")
+    ref_t = c_oracle.step(sd, noisy, clean, n, ci, True, "mse", precision="f64")
+
+    def run(h3u, training):
+        monkeypatch.setenv("WUNET_H3U", h3u)
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
+        m, _, _ = _build(n, ci, eng)
+        if not training:
+            m.eval()
+            with torch.no_grad():
+                return m(torch.from_numpy(noisy)).numpy(), None
+        m.train()
+        crit = pkg_loss.mse_loss()
+        crit._engine_override = eng
+        out = m(torch.from_numpy(noisy))
+        crit(torch.from_numpy(clean), out).backward()
+        return out.detach().numpy(), {k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+
+    e_old, _ = run("0,0", False)
+    e_new, _ = run("256,256", False)
+    assert np.abs(e_new - ref_e["out"]).max() < 2e-6 and np.abs(e_new - e_old).max() < 1e-6
+    if ci == 24:
+        assert not np.array_equal(e_new, e_old)     # (really another kernel: these layers' K tails vs whole chunks add in another order)
+    t_old, g_old = run("0,0", True)
+    t_new, g_new = run("256,256", True)
+    assert np.abs(t_new - ref_t["out"]).max() < 2e-5
+    for k, r in ref_t["grads"].items():
+        if k.endswith(".0.bias") and not k.startswith("out"):
+            assert np.all(g_new[k] == 0.0), k
+            continue
+        scale = max(np.abs(r).max(), 1e-6)
+        assert np.abs(g_new[k] - r).max() < 3e-4 * scale + 1e-6, (k, np.abs(g_new[k] - r).max(), scale)
+        assert np.abs(g_new[k] - g_old[k]).max() < 1e-4 * scale + 1e-7, k

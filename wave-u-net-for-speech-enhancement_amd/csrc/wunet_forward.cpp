@@ -100,7 +100,8 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             PackH3Desc& d = tab.d[nd++];
             d.w = params[4 * i]; d.hi = wh + l.h3f_wpk; d.lo = wl + l.h3f_wpk;
             d.Cout = l.cout; d.Cin = l.cin; d.taps = l.taps; d.rows = l.cout; d.kch = l.cin; d.mtiles = l.h3f_mtp; d.nch = l.h3f_nch; d.transposed = 0;
-            d.ntt = l.h3f_ntt; d.nfull = ((l.cin + 7) / 8) / 4; d.ns = h3_stage_count(l.cin, l.taps, l.h3f_ntt);
+            // (conv_h3u_kernel walks whole chunks: the layers it runs in this mode get a pack without K tail - never longer than the one with)
+            d.ntt = (training ? l.h3u_train : l.h3u) ? 0 : l.h3f_ntt; d.nfull = ((l.cin + 7) / 8) / 4; d.ns = h3_stage_count(l.cin, l.taps, d.ntt);
             d.wmax = ws + c->wmax_off + (size_t)WUNET_WMAX_PARTS * i; d.wsc = ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2;
             d.bf = c->bf;
         }
@@ -162,7 +163,9 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         }
         // 2a. materialise the conv input: BN scale/shift + LeakyReLU + decimation, or + x2 upsample + skip concat
         const float* xin = noisy;
-        if (i > 0) {
+        // conv_h3u_kernel builds its operand itself (wunet_h3u.h): no operand pass for this layer
+        const bool use_u = i > 0 && (training ? l.h3u_train : l.h3u);
+        if (i > 0 && !use_u) {
             const LayerPlan& p = c->ly[l.src0];
             PrepArgs pa{};
             pa.z0 = ws + p.z; pa.a0 = ws + p.a; pa.s0 = ws + p.s; pa.x = ws + l.xin;
@@ -185,7 +188,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 ph.bf = c->bf;
                 if (l.kind == LK_DECIM && training) {
                     const int dj = 2 * c->n - i + 1;             // the decoder layer that concatenates this pass's producer
-                    if (dj < c->NL && c->ly[dj].skip_from == i) {
+                    if (dj < c->NL && c->ly[dj].skip_from == i && !c->ly[dj].h3u_train) {      // (conv_h3u_kernel writes its whole operand)
                         const LayerPlan& dl = c->ly[dj];
                         ph.sh = reinterpret_cast<wunet_half*>(ws + dl.xh); ph.sl = reinterpret_cast<wunet_half*>(ws + dl.xl);
                         ph.SC8 = (dl.cin + 7) / 8; ph.sc8off = dl.c0 / 8;
@@ -260,6 +263,25 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                          ws + l.z, training ? ws + c->stats_off : (float*)nullptr, c->B, l.cout, l.L, l.logL,
                          ev_epi ? ws + l.a : (const float*)nullptr, ev_epi ? ws + l.s : (const float*)nullptr, ev_epi ? xrows : (float*)nullptr, l.Lt);
             prof_end(st);
+        } else if (use_u) {
+            const LayerPlan& p = c->ly[l.src0];
+            const LayerPlan& k = c->ly[l.src1];
+            ConvH3uArgs u{};
+            u.z0 = ws + p.z; u.a0 = ws + p.a; u.s0 = ws + p.s; u.z1 = ws + k.z; u.a1 = ws + k.a; u.s1 = ws + k.s;
+            u.xb0 = fslot + (size_t)WUNET_SLOT_FLOATS * l.src0 + 4; u.xb1 = fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4;
+            u.xsc = fslot + (size_t)WUNET_SLOT_FLOATS * i;
+            u.up_scale = (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1); u.Lt = l.Lt; u.C0 = l.c0; u.C1 = l.cin - l.c0;
+            u.wh = reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk;
+            u.wdelta = (unsigned)((const char*)(ws + c->h3_wf_lo) - (const char*)(ws + c->h3_wf_hi));
+            u.bias = params[4 * i + 1]; u.sc2 = fslot + (size_t)WUNET_SLOT_FLOATS * i + 2;
+            u.out = ws + l.z; u.stats = training ? ws + c->stats_off : nullptr;
+            u.ev_a = ev_epi ? ws + l.a : nullptr; u.ev_s = ev_epi ? ws + l.s : nullptr; u.xrows = ev_epi ? xrows : nullptr;
+            if (training && save_for_backward) {        // the weight gradient reads the split operand
+                u.oxh = reinterpret_cast<wunet_half*>(ws + l.xh); u.oxl = reinterpret_cast<wunet_half*>(ws + l.xl);
+            }
+            u.B = c->B; u.Cout = l.cout; u.L = l.L;
+            const int rc = launch_conv_h3u(u, l.h3f_mrep, l.h3f_mtp, l.cin, st);
+            if (rc) return rc;
         } else if (l.h3f) {
             // fp16-split GEMM: split the materialised input, then 3 MFMA passes on the 2.5 PF pipe
             wunet_half* xh = reinterpret_cast<wunet_half*>(ws + l.xh);

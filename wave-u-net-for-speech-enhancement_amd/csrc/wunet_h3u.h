@@ -1,0 +1,486 @@
+// conv_h3u_kernel: the 5-tap conv of a decoder level (unet_basic.py:25-26, 93-95) with the operand pass INSIDE the kernel.
+// conv_h3d_kernel reads its input from the split operand arrays an elementwise pass (prep_h3_kernel) wrote: per value 4 bytes
+// written + 4 read, on top of the fp32 sources the pass reads.  Here the block builds the x tile itself from what the producers
+// left in HBM - the raw fp32 conv outputs z of the previous decoder level (half resolution) and of the skip encoder level -
+// BatchNorm scale / shift, LeakyReLU, the x2 linear upsample with ATen's fp32 coordinates, the concat, the power-of-two scale and
+// the hi / lo split all happen on the way into LDS.  prep_h3_kernel disappears for the layer and the conv reads 2 (upsampled
+// half) or 4 (skip half) bytes per operand value instead of 4 + 4.
+//
+// Work split inside the block (512 threads, one block per CU): WAVE SPECIALISATION.  Waves 0-3 are the conv_h3d_kernel MFMA
+// waves (same LDS images, same fragments, same MFMA order per accumulator); waves 4-7 are loaders - loader wave w owns channel
+// group w of the stage's chunk of 32 channels: global loads -> VALU -> ds_write_b128 of the NEXT stage's x tile, and the LDS-DMA
+// of the next W sub-tile.  Every SIMD hosts one MFMA wave and one loader wave, so the matrix pipe and the vector ALU / memory
+// pipes of a SIMD are fed by different instruction streams and overlap without any software pipelining inside a wave.  x tile
+// and W sub-tile are double-buffered: ONE workgroup barrier per stage (the buffer a stage reads was completed before the
+// barrier; the buffer the loaders fill was last read in the previous stage).
+// No K tail (the forward pack of such a layer is built without one), no K split (levels >= 256 samples only).
+#pragma once
+#include "wunet_h3.h"
+// WUNET_H3U_ABL: ablation builds of tools/h3u_ablation.sh (parts of the kernel compiled out: 1 no global loads, 2 no conversion arithmetic,
+// 4 no MFMAs, 8 no W DMA, 16 no conversion at all (no LDS writes), 32 no fragment reads and no MFMAs); 0 in the product
+#ifndef WUNET_H3U_ABL
+#define WUNET_H3U_ABL 0
+#endif
+
+struct ConvH3uArgs {
+    const float* z0; const float* a0; const float* s0;     // upsampled branch: producer's z [B][C0][L/2], its BatchNorm scale / shift
+    const float* z1; const float* a1; const float* s1;     // skip branch: [B][C1][L]
+    const float* xb0; const float* xb1;                    // activation bounds of the two producers (their slot [4]): the x scale derives from them
+    float* xsc;                                            // {scale, 1/scale} of the operand, published by block 0
+    float up_scale;                                        // (float)(Lt/2 - 1) / (Lt - 1), computed on the host like ATen does
+    int Lt;                                                // samples of a row that exist (<= L, the row stride)
+    int C0, C1, C8;                                        // channels of the two branches (multiples of 8), groups of 8 in all
+    const wunet_half* wh; unsigned wdelta;                 // forward pack without K tail; the lo pack lies wdelta bytes behind
+    const float* bias; const float* sc2;                   // conv bias; {scale, 1/scale} of the packed weights
+    float* out; float* stats;                              // [B][Cout][L]; nullptr or [Cout][ntiles][2]
+    const float* ev_a; const float* ev_s; float* xrows;    // eval mode: this layer's BatchNorm scale / shift, its xb slot (see ConvH3Args)
+    wunet_half* oxh; wunet_half* oxl;                      // nullptr, or the split operand [B][C8][L][8] written out as well (training: the weight gradient reads it)
+    int B, Cout, L, logL, NS, ntiles, mblocks;
+};
+
+// (the helpers of the elementwise operand pass - wunet_x_scale, wunet_split_rt - live in wunet_h3_elem.h, which the host translation
+// units include; the kernel only needs this one)
+__device__ __forceinline__ void wunet_h3u_x_scale(const float* xb0, const float* xb1, float& s, float& inv)
+{
+    wunet_pow2_scale(fmaxf(xb0[0], xb1 ? xb1[0] : 0.0f), s, inv);
+}
+
+// Loader waves' barrier: every LDS write and every DMA piece of the wave has landed - but NOT the `younger` (0, 9 or 10, wave-uniform)
+// global loads the wave issued AFTER its last DMA piece: those are the prefetch of a tile two stages ahead and stay in flight across
+// the barrier (memory operations return in order: at most `younger` outstanding means everything older has completed).  Waiting for
+// vmcnt(0) here made every stage one full memory latency long (2.5 - 3 us per stage instead of ~1).
+__device__ __forceinline__ void wunet_loader_barrier(int younger)
+{
+#ifdef WUNET_EMU
+    (void)younger;
+    emu::block_barrier();
+#else
+    if (younger >= 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (younger == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
+// ---- loader side.  Loader wave `cw` builds channel group ch*4 + cw of the x tile [hi|lo][4][COLS, de-interleaved][8]: the 260 columns
+// 6 .. 265 a 5-tap fragment reads (column c = sample l0 - 8 + c).  Lane k owns the four samples P .. P+3, P = l0 - 2 + 4k, of the
+// group's 8 channels: ONE 16-byte load per channel - skip branch: the samples themselves; upsampled branch: the four source samples
+// wb .. wb+3, wb = (P-2)/2, which are exactly what ATen's coordinates of the four outputs touch ((i0, i1) = (wb, wb+1), (wb+1, wb+2),
+// (wb+1, wb+2), (wb+2, wb+3); checked against the exact fp32 coordinates per lane, any other outcome - the clamped ends of a row -
+// takes the general path) - so a lane activates 4 source values per channel instead of 8 and a tile costs 8 load instructions per
+// wave, few enough to keep THREE tiles in flight (WunetH3uRaw: 34 registers).  The last 4 columns (262 .. 265) are one value per lane
+// of lanes 0 .. 31.  Two steps: wunet_h3u_issue (the loads) and, stages later, wunet_h3u_convert (prep_h3_kernel's arithmetic:
+// BatchNorm scale / shift, LeakyReLU, ATen's upsample weights, scale, split; LDS writes; in training also the operand's copy in HBM).
+struct WunetH3uRaw { wunet_f4 q[8]; float ma, mb; };
+struct WunetH3uTile { int b, l0, mt0, ch; };
+
+// 16 bytes from a 4-byte aligned address
+__device__ __forceinline__ wunet_f4 wunet_ld4u(const float* p)
+{
+#ifdef WUNET_EMU
+    return wunet_ld4(p);
+#else
+    typedef float wunet_f4u __attribute__((ext_vector_type(4), aligned(4)));
+    return *reinterpret_cast<const wunet_f4u*>(p);
+#endif
+}
+
+// ONE straight sequence of 10 loads whatever the group is (addresses selected, not branches: a value that is "loaded on one path and kept on
+// another" becomes a copy of the loaded registers, and a copy waits for the load - the prefetch would be serialised): a group beyond C8
+// re-reads the first skip group (its values are dropped), the skip branch's second single load repeats the first.  Returns the number of
+// load instructions issued (10).
+__device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw& R, const WunetH3uTile& T, int cw, int lane)
+{
+    if (WUNET_H3U_ABL & 1) return 0;
+    const int c8 = wunet_uniform(T.ch * 4 + cw);
+    const int L = A.L, Lh = L >> 1, Lth = A.Lt >> 1;
+    const bool none = c8 >= A.C8, up = !none && c8 * 8 < A.C0;
+    const int P = T.l0 - 2 + 4 * lane;
+    const int e_m = (lane >> 2) & 7, p_m = T.l0 + 254 + (lane & 3);    // the value of the last 4 columns this lane owns (lanes 0 .. 31)
+    const bool in_m = lane < 32 && p_m < A.Lt;
+    int wb = (T.l0 >> 1) - 2 + 2 * lane;
+    wb = wb < 0 ? 0 : (wb > Lth - 4 ? Lth - 4 : wb);
+    const int pc = P < 0 ? 0 : (P > L - 4 ? L - 4 : P);
+    int i0, i1;
+    float w0, w1;
+    wunet_up_coord(in_m ? p_m : 0, Lth, A.up_scale, i0, i1, w0, w1);
+    const size_t rs = up ? (size_t)Lh : (size_t)L;                       // row stride of the source
+    const float* const zrow = up ? A.z0 + ((size_t)T.b * A.C0 + c8 * 8) * Lh : A.z1 + ((size_t)T.b * A.C1 + (none ? 0 : c8 * 8 - A.C0)) * L;
+    const float* const zq = zrow + (up ? wb : pc);
+    const int m0 = up ? i0 : (in_m ? p_m : 0), m1 = up ? i1 : m0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) R.q[e] = wunet_ld4u(zq + (size_t)e * rs);
+    R.ma = zrow[(size_t)e_m * rs + m0];
+    R.mb = zrow[(size_t)e_m * rs + m1];
+    return 10;
+}
+
+__device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
+                                                  int lane, float xscale, const float* coef)
+{
+    constexpr int COLS = 272, Q4 = COLS / 4;
+    if (WUNET_H3U_ABL & 16) return;
+    if (WUNET_H3U_ABL & 64) {                       // the loads stay alive (their registers are summed), nothing else of the conversion
+        float t = R.ma + R.mb;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += R.q[e][0] + R.q[e][1] + R.q[e][2] + R.q[e][3];
+        if (t == 123.456f) xs[lane] = 1;
+        return;
+    }
+    const int c8 = wunet_uniform(T.ch * 4 + cw);
+    const int L = A.L, Lth = A.Lt >> 1;
+    const bool none = (c8 >= A.C8) || (WUNET_H3U_ABL & 2), up = !none && c8 * 8 < A.C0;
+    const bool write_out = A.oxh != nullptr && T.mt0 == 0 && !none;
+    // BatchNorm scale / shift of the group's channels from the block's LDS table (a loaded from global memory here would be one more
+    // memory round trip per stage - and its wait would drain the prefetched tiles with it)
+    float av[8], sv[8];
+    {
+        const int cc = none ? 0 : c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { av[e] = coef[cc + e]; sv[e] = coef[A.C8 * 8 + cc + e]; }
+    }
+    // Rows are whole (Lt == L: the planner keeps padded lengths off this kernel), so the only lane whose window was clamped is the one
+    // at the start of a row (P = -2: its loads started two elements later): `edge`.  No branch, no second code path: a few selects.
+    const int P = T.l0 - 2 + 4 * lane;
+    const bool edge = P < 0;
+    float vals[4][8];                               // [sample P + j][channel]
+    if (up) {
+        // ATen's coordinates of the outputs P .. P+3 (wunet_up_coord: fp32, as the reference computes them).  Their source pairs are
+        // (wb, wb+1), (wb+1, wb+2), (wb+1, wb+2), (wb+2, wb+3) with wb = (P-2)/2 - i0(j) = (j-1) >> 1 for every j >= 1 at these lengths;
+        // output 0 of a row has i0 = 0 with weight 1 on it, which the clamped source index -1 -> 0 reproduces.
+        float w0[4], w1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int i0, i1;
+            wunet_up_coord(P + j < 0 ? 0 : P + j, Lth, A.up_scale, i0, i1, w0[j], w1[j]);
+            w0[j] *= xscale; w1[j] *= xscale;            // (a power of two: exact, the sum rounds as the unscaled one)
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = wunet_lrelu(av[e] * R.q[e][k] + sv[e]);
+            // sources wb .. wb+3 with the row's left clamp: (0, 0, 0, 1) from a window that started at 0
+            const float t0 = u[0], t1 = edge ? u[0] : u[1], t2 = edge ? u[0] : u[2], t3 = edge ? u[1] : u[3];
+            vals[0][e] = w0[0] * t0 + w1[0] * t1;
+            vals[1][e] = w0[1] * t1 + w1[1] * t2;
+            vals[2][e] = w0[2] * t1 + w1[2] * t2;
+            vals[3][e] = w0[3] * t2 + w1[3] * t3;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = xscale * wunet_lrelu(av[e] * R.q[e][k] + sv[e]);
+            vals[0][e] = u[0]; vals[1][e] = u[1];
+            vals[2][e] = edge ? u[0] : u[2];             // (a window that started at sample 0: samples 0, 1 are its first two)
+            vals[3][e] = edge ? u[1] : u[3];
+        }
+    }
+    bool inside[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inside[j] = !none && !(edge && j < 2);      // samples -2, -1: the conv's zero padding
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wunet_h8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            wunet_half x, y;
+            wunet_split_h(inside[j] ? vals[j][e] : 0.0f, x, y);
+            wunet_put_half(h, e, x);
+            wunet_put_half(l, e, y);
+        }
+        const int col = 4 * lane + 6 + j;
+        const int pw = (cw * COLS + (col & 3) * Q4 + (col >> 2)) * 8;
+        wunet_sth8(xs + pw, h);
+        wunet_sth8(xs + 4 * COLS * 8 + pw, l);
+        // (training) the tile's own 256 samples of the operand also go to HBM, once per tile: the weight gradient reads them
+        if (write_out && col >= 8 && col < 264) {
+            const size_t o = (((size_t)T.b * A.C8 + c8) * L + (size_t)(P + j)) * 8;
+            wunet_sth8(A.oxh + o, h);
+            wunet_sth8(A.oxl + o, l);
+        }
+    }
+    // columns 262 .. 265 (samples l0 + 254 .. 257): channel lane >> 2, sample lane & 3 of lanes 0 .. 31, two bytes per plane each
+    if (lane < 32) {
+        const int e_m = lane >> 2, p_m = T.l0 + 254 + (lane & 3);
+        const bool in_m = !none && p_m < A.Lt;
+        float am = av[0], sm = sv[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) { am = e_m == e ? av[e] : am; sm = e_m == e ? sv[e] : sm; }
+        float v;
+        if (up) {
+            int i0, i1;
+            float w0, w1;
+            wunet_up_coord(in_m ? p_m : 0, Lth, A.up_scale, i0, i1, w0, w1);
+            w0 *= xscale; w1 *= xscale;
+            v = w0 * wunet_lrelu(am * R.ma + sm) + w1 * wunet_lrelu(am * R.mb + sm);
+        } else v = xscale * wunet_lrelu(am * R.ma + sm);
+        wunet_half x, y;
+        wunet_split_h(in_m ? v : 0.0f, x, y);
+        const int col = 262 + (lane & 3);
+        const int pw = (cw * COLS + (col & 3) * Q4 + (col >> 2)) * 8 + e_m;
+        xs[pw] = x;
+        xs[4 * COLS * 8 + pw] = y;
+        if (write_out && col < 264) {
+            const size_t o = (((size_t)T.b * A.C8 + c8) * L + (size_t)p_m) * 8 + e_m;
+            A.oxh[o] = x;
+            A.oxl[o] = y;
+        }
+    }
+}
+
+template <int M_REP>
+__global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uArgs A)
+{
+    constexpr int PAD = 2, TG = 5;
+    constexpr int COLS = 272, Q4 = COLS / 4;
+    constexpr int XP = 2 * 4 * COLS;              // 16-byte pieces of one x tile (hi + lo)
+    constexpr int WPM = TG * 64;
+    constexpr int WP = 2 * M_REP * WPM;           // pieces of one W sub-tile
+    static_assert(WPM == 320, "W run = 256 + 64 pieces");
+    WUNET_DYN_SMEM(smem);
+    wunet_half* const xs0 = reinterpret_cast<wunet_half*>(smem);          // [2][hi|lo][4][COLS, de-interleaved][8]
+    wunet_half* const ws0 = xs0 + 2 * XP * 8;                              // [2][hi|lo][M_REP][TG][4][16][8]
+    float* const red = reinterpret_cast<float*>(ws0 + 2 * WP * 8);        // [4 waves][M_REP * 16][2] statistics hand-over
+    float* const coef = red + WUNET_WAVES * M_REP * 32 + 4;                // [a | s][C8 * 8]: BatchNorm scale / shift of the operand's channels
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wunet_uniform(tid >> 6);
+    const int cw = wave & 3;                      // MFMA wave / loader wave index
+    const int L = A.L;
+    const int G = gridDim.x, nitems = A.ntiles * A.mblocks;
+    if ((int)blockIdx.x >= nitems) return;
+    const int nmy = (nitems - (int)blockIdx.x + G - 1) / G;           // work items (position tile, row block) of this block: blockIdx.x + k G
+    const bool want_stats = A.stats != nullptr;
+
+    float xs_ = 1.0f, xinv_ = 1.0f;
+    wunet_h3u_x_scale(A.xb0, A.xb1, xs_, xinv_);
+    if (blockIdx.x == 0 && tid == 0 && A.xsc) { A.xsc[0] = xs_; A.xsc[1] = xinv_; }
+
+    for (int c = tid; c < A.C8 * 8; c += 2 * WUNET_THREADS) {
+        const bool u = c < A.C0, k = c < A.C0 + A.C1;
+        coef[c] = u ? A.a0[c] : k ? A.a1[c - A.C0] : 0.0f;
+        coef[A.C8 * 8 + c] = u ? A.s0[c] : k ? A.s1[c - A.C0] : 0.0f;
+    }
+    __syncthreads();
+    // Both roles run the SAME sequence of workgroup barriers: one per stage (the stage's buffers are complete - the loaders waited for
+    // their DMA pieces and LDS writes - and every MFMA wave has read the last fragment of the previous stage, whose buffers the
+    // loaders may now refill), plus, with statistics, one per item (hand-over of the waves' sums).
+    if (wave >= WUNET_WAVES) {
+        // ================================================================ loader waves
+        const wunet_lds_t ws_a = wunet_lds_addr(ws0);
+        const unsigned wo_all = (unsigned)(cw * 64 + lane) * 16u, wo_rest = (256u + (unsigned)lane) * 16u;
+        const int T = nmy * A.NS;                 // stages of this block, tile t = (item t / NS, chunk t % NS)
+#define WUNET_H3U_TILE(T_, OUT_)                                                                                   \
+    WunetH3uTile OUT_;                                                                                             \
+    {                                                                                                              \
+        const int k_ = (T_) / A.NS, v_ = (int)blockIdx.x + k_ * G, tile_ = v_ / A.mblocks;                         \
+        OUT_.ch = (T_) - k_ * A.NS; OUT_.mt0 = (v_ - tile_ * A.mblocks) * M_REP;                                   \
+        OUT_.b = (tile_ * 256) >> A.logL; OUT_.l0 = (tile_ * 256) & (L - 1);                                       \
+    }
+        // W sub-tile of a stage: per (plane, m-tile) a contiguous run of 320 pieces in the pack and in LDS
+#define WUNET_H3U_DMA_W(TL_, P_)                                                                                   \
+    {                                                                                                              \
+        const char* const wbase_ = reinterpret_cast<const char*>(A.wh) + (long long)((((size_t)(TL_).mt0 * A.NS + (TL_).ch) * TG * 64) * 16); \
+        _Pragma("unroll") for (int sub = 0; sub < 2 * M_REP; ++sub) {                                              \
+            const char* const run_ = wbase_ + (long long)(sub % M_REP) * A.NS * (TG * 64 * 16) + (sub >= M_REP ? (long long)A.wdelta : 0LL); \
+            if (!(WUNET_H3U_ABL & 8)) wunet_dma16s(run_, wo_all, ws_a + ((P_) * WP + sub * WPM + cw * 64) * 16);  \
+            if (!(WUNET_H3U_ABL & 8) && cw == (sub & 3)) wunet_dma16s(run_, wo_rest, ws_a + ((P_) * WP + sub * WPM + 256) * 16); \
+        }                                                                                                          \
+    }
+        // Tile t's loads are issued three stages before the MFMA waves need it: in stage t the loaders convert tile t + 1 (loaded two
+        // stages ago) into the other buffer while the loads of tiles t + 2 and t + 3 are in flight - memory latency under load (2 - 3 us)
+        // is several stage times.  R0 / R1 / R2 rotate by unrolling, not by moves.
+        // (Every stage of the steady loop issues its 10 prefetch loads UNCONDITIONALLY - past the block's last tile it re-reads that tile - and
+        // the loop body has no join between an "issued" and a "not issued" path: at such a join hipcc's wait-count bookkeeping has to assume
+        // the older loads are the youngest ones outstanding, and the first use of a tile loaded two stages ago then waits for the loads
+        // issued a moment before it - the prefetch collapses to one memory latency per stage.)
+        WunetH3uRaw R0, R1, R2;
+        {
+            WUNET_H3U_TILE(0, t0)
+            WUNET_H3U_TILE(T > 1 ? 1 : 0, t1)
+            WUNET_H3U_TILE(T > 2 ? 2 : T - 1, t2)
+            wunet_h3u_issue(A, R0, t0, cw, lane);
+            wunet_h3u_issue(A, R1, t1, cw, lane);
+            WUNET_H3U_DMA_W(t0, 0)
+            wunet_h3u_issue(A, R2, t2, cw, lane);
+            wunet_h3u_convert(A, R0, t0, xs0, cw, lane, xs_, coef);
+        }
+        // stage t (< T - 1): CUR_ holds the loads of tile t + 1, FREE_ (tile t's, converted a stage ago) takes those of tile t + 3; 10 loads
+        // (tile t + 3's) are younger than the stage's last DMA piece at the next barrier
+#define WUNET_H3U_LOADER_STAGE(CUR_, FREE_)                                                                        \
+    {                                                                                                              \
+        wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                                                        \
+        WUNET_H3U_TILE(t + 1, tn)                                                                                  \
+        WUNET_H3U_DMA_W(tn, (t + 1) & 1)                                                                           \
+        WUNET_H3U_TILE(t + 3 < T ? t + 3 : T - 1, tnn)                                                             \
+        wunet_h3u_issue(A, FREE_, tnn, cw, lane);                                                                  \
+        wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, xs_, coef);                         \
+        if (want_stats && (t + 1) % A.NS == 0) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                 \
+        ++t;                                                                                                       \
+    }
+        int t = 0;
+        while (t < T - 1) {
+            WUNET_H3U_LOADER_STAGE(R1, R0)
+            if (t >= T - 1) break;
+            WUNET_H3U_LOADER_STAGE(R2, R1)
+            if (t >= T - 1) break;
+            WUNET_H3U_LOADER_STAGE(R0, R2)
+        }
+        // the last stage: nothing left to prepare
+        wunet_loader_barrier(0);
+        if (want_stats) wunet_loader_barrier(0);
+#undef WUNET_H3U_LOADER_STAGE
+#undef WUNET_H3U_DMA_W
+#undef WUNET_H3U_TILE
+        return;
+    }
+
+    // ================================================================ MFMA waves (conv_h3d_kernel's fragments and MFMA order)
+    const int q = lane >> 4, i16 = lane & 15;
+    const int ll0 = cw * 64 + i16 * 4;            // this lane's 4 positions cw*64 + 4*i16 .. +3
+    const int boff = (q * COLS + (ll0 >> 2)) * 8;
+    const int aoff = (q * 16 + i16) * 8;
+    int par = 0;                                  // buffer the coming stage reads
+    float amax_run = 0.0f;
+    for (int k = 0; k < nmy; ++k) {
+        const int v = (int)blockIdx.x + k * G, tile = v / A.mblocks, mblk = v - tile * A.mblocks;
+        const int b = (tile * 256) >> A.logL, l0 = (tile * 256) & (L - 1), mt0 = mblk * M_REP;
+        wunet_f4 acc[M_REP][4];
+#pragma unroll
+        for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
+        for (int st = 0; st < A.NS; ++st) {
+            wunet_wait_lds_barrier();
+            if (WUNET_H3U_ABL & 32) { par ^= 1; continue; }
+            const wunet_half* const xs = xs0 + par * XP * 8;
+            const wunet_half* const ws = ws0 + par * WP * 8;
+            wunet_h8 fh[TG + 3], fl[TG + 3];
+#pragma unroll
+            for (int e = 0; e < TG + 3; ++e) {
+                const int ec = e + 8 - PAD;
+                const int po = ((ec & 3) * Q4 + (ec >> 2)) * 8;
+                fh[e] = wunet_ldh8(xs + boff + po);
+                fl[e] = wunet_ldh8(xs + 4 * COLS * 8 + boff + po);
+            }
+            wunet_h8 ah[2][M_REP], al[2][M_REP];
+#define WUNET_H3U_LOAD_A(BUF_, TL_)                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        ah[BUF_][mt] = wunet_ldh8(ws + ((mt * TG + (TL_)) * 64) * 8 + aoff);                                      \
+        al[BUF_][mt] = wunet_ldh8(ws + ((M_REP + mt) * TG + (TL_)) * 64 * 8 + aoff);                              \
+    }
+#define WUNET_H3U_PASS(WHICH_, BUF_, TL_)                                                                         \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                          \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
+            if (WUNET_H3U_ABL & 4) { if ((WHICH_) == 0 && (TL_) == 0) acc[mt][nt][0] += (float)al[BUF_][mt][0] + (float)fh[nt][0] + (float)ah[BUF_][mt][1] + (float)fl[nt][1]; } \
+            else if ((WHICH_) == 0) acc[mt][nt] = wunet_mfma16h(al[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);       \
+            else if ((WHICH_) == 1) acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fl[(TL_) + nt], acc[mt][nt]);       \
+            else acc[mt][nt] = wunet_mfma16h(ah[BUF_][mt], fh[(TL_) + nt], acc[mt][nt]);                          \
+        }
+#define WUNET_H3U_STEP(TL_)                                                                                       \
+    {                                                                                                             \
+        constexpr int tl = (TL_);                                                                                 \
+        if (tl + 1 < TG) {                                                                                        \
+            if (tl & 1) { WUNET_H3U_LOAD_A(0, tl + 1) } else { WUNET_H3U_LOAD_A(1, tl + 1) }                      \
+        }                                                                                                         \
+        wunet_sched_fence();                                                                                      \
+        if (tl & 1) { WUNET_H3U_PASS(0, 1, tl) WUNET_H3U_PASS(1, 1, tl) WUNET_H3U_PASS(2, 1, tl) }               \
+        else { WUNET_H3U_PASS(0, 0, tl) WUNET_H3U_PASS(1, 0, tl) WUNET_H3U_PASS(2, 0, tl) }                      \
+    }
+            WUNET_H3U_LOAD_A(0, 0)
+            WUNET_H3U_STEP(0) WUNET_H3U_STEP(1) WUNET_H3U_STEP(2) WUNET_H3U_STEP(3) WUNET_H3U_STEP(4)
+#undef WUNET_H3U_STEP
+#undef WUNET_H3U_PASS
+#undef WUNET_H3U_LOAD_A
+            par ^= 1;
+        }
+
+        // ---- epilogue (conv_h3d_kernel's): un-scale, bias, store, BatchNorm statistics of the bias-free conv / eval activation bound.
+        // The loaders are filling the next item's first buffers meanwhile.
+        {
+            const float inv = xinv_, inv2 = A.sc2 ? A.sc2[1] : 1.0f;
+            float amax = 0.0f;
+            float bvs[M_REP][4];
+#pragma unroll
+            for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = (mt0 + mt) * 16 + q * 4 + r;
+                    bvs[mt][r] = (A.bias && co < A.Cout) ? A.bias[co] : 0.0f;
+                }
+            float* const prow = A.out + ((size_t)b * A.Cout + mt0 * 16 + q * 4) * L + (l0 + ll0);
+            const bool full = (mt0 + M_REP) * 16 <= A.Cout;
+#define WUNET_H3U_ROWS(STATS_, GUARD_, EVAL_)                                                                     \
+    float eas[M_REP][4], ess[M_REP][4];                                                                           \
+    if (EVAL_) {                                                                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                      \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+                const int co = (mt0 + mt) * 16 + q * 4 + r;                                                       \
+                eas[mt][r] = co < A.Cout ? A.ev_a[co] : 0.0f;                                                     \
+                ess[mt][r] = co < A.Cout ? A.ev_s[co] : 0.0f;                                                     \
+            }                                                                                                     \
+    }                                                                                                             \
+    _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};                                         \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
+            const int co = (mt0 + mt) * 16 + q * 4 + r;                                                           \
+            const float bv = bvs[mt][r];                                                                          \
+            wunet_f4 o;                                                                                           \
+            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
+                const float vv = acc[mt][nt][r] * inv * inv2;                                                     \
+                if (STATS_) { s1[r] += vv; s2[r] = fmaf(vv, vv, s2[r]); }                                         \
+                o[nt] = vv + bv;                                                                                  \
+            }                                                                                                     \
+            if (!(GUARD_) || co < A.Cout) {                                                                       \
+                wunet_st4(prow + (size_t)(mt * 16 + r) * L, o);                                                   \
+                if (EVAL_) {                                                                                      \
+                    const float ea = eas[mt][r], es = ess[mt][r];                                                 \
+                    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));  \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (STATS_) {                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+                s1[r] = wunet_row16_sum(s1[r]);                                                                   \
+                s2[r] = wunet_row16_sum(s2[r]);                                                                   \
+                if (i16 == 0) {                                                                                   \
+                    float* rp = red + ((cw * M_REP + mt) * 16 + q * 4 + r) * 2;                                   \
+                    rp[0] = s1[r];                                                                                \
+                    rp[1] = s2[r];                                                                                \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+    }
+            if (A.xrows) { WUNET_H3U_ROWS(false, true, true) }
+            else if (want_stats) { if (full) { WUNET_H3U_ROWS(true, false, false) } else { WUNET_H3U_ROWS(true, true, false) } }
+            else { if (full) { WUNET_H3U_ROWS(false, false, false) } else { WUNET_H3U_ROWS(false, true, false) } }
+#undef WUNET_H3U_ROWS
+            if (A.xrows) {                        // eval: the wave's running maximum of the activation bound (no hand-over: one atomic per wave at the end)
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) amax = fmaxf(amax, wunet_shfl_xor(amax, m));
+                amax_run = fmaxf(amax_run, amax);
+            }
+        }
+        // one statistics row per tile (256 positions): the four MFMA waves' sums are added in wave order
+        if (want_stats) {
+            wunet_wait_lds_barrier();
+            if (tid < M_REP * 16) {
+                const float* rp = red + tid * 2;
+                float t1 = 0.0f, t2 = 0.0f;
+#pragma unroll
+                for (int w = 0; w < WUNET_WAVES; ++w) {
+                    t1 += rp[w * M_REP * 32];
+                    t2 += rp[w * M_REP * 32 + 1];
+                }
+                const int co = mt0 * 16 + tid;
+                if (co < A.Cout) {
+                    float* stp = A.stats + ((size_t)co * A.ntiles + tile) * 2;
+                    stp[0] = t1;
+                    stp[1] = t2;
+                }
+            }
+        }
+    }
+    if (A.xrows && lane == 0) wunet_atomic_absmax(A.xrows, amax_run);      // one atomic per MFMA wave into the layer's xb slot
+}

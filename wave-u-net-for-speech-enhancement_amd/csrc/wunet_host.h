@@ -19,6 +19,7 @@
 
 #include "wunet_kernels.h"
 #include "wunet_h3.h"
+#include "wunet_h3u.h"
 #include "wunet_launch.h"
 #include "wunet_hip.h"
 
@@ -82,6 +83,7 @@ struct LayerPlan {
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
     int skip_from;                // decoder layer: > 0 = its skip half is written by the operand pass of encoder-side layer skip_from
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps, h3w_tp;   // weight gradient uses wgrad_h3_kernel
+    int h3u, h3u_train;           // conv_h3u_kernel (operand pass fused into the conv's loader waves) runs the eval / also the training forward
     int feeds_h3;                 // the layer's activation is the (or a) source of a conv input that exists in the split layout
     size_t xh, xl, xzp;           // split activated input (float offsets): hi plane, lo plane right behind it, then 16 zero bytes (DMA pad)
     size_t gzh, gzl, gzp;         // split scaled g_z (float offsets), likewise
@@ -137,6 +139,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a = nullptr, const float* ev_s = nullptr,
                    float* xrows = nullptr, int bf = 0, int ntt = 0);
+int launch_conv_h3u(const ConvH3uArgs& a, int mrep, int mtiles_p, int kch, hipStream_t st);
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
                     const float* sc, const float* sc2, float* part, int B, hipStream_t st, int bf = 0);
 int launch_backward_packs(wunet_ctx* c, const float* const* params, float* ws, hipStream_t st);

@@ -149,6 +149,29 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     return 0;
 }
 
+// conv_h3u_kernel: one block of 8 waves per CU walks the (tile, row block) items; the caller filled everything of `a` but the tiling
+int launch_conv_h3u(const ConvH3uArgs& a0, int mrep, int mtiles_p, int kch, hipStream_t st)
+{
+    ConvH3uArgs a = a0;
+    const double posn = (double)a.B * a.L;
+    a.logL = ilog2(a.L);
+    a.C8 = (kch + 7) / 8;
+    a.NS = (a.C8 + 3) / 4;
+    a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
+    const size_t smem = (size_t)(2 * 2 * 4 * 272 + 2 * 2 * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4 + 2 * a.C8 * 8) * sizeof(float);
+    const int nitems = a.ntiles * a.mblocks;
+    int gx = h3_grid_cap() / 2;                  // one block per CU
+    if (gx > nitems) gx = nitems;
+    char pname[64];
+    snprintf(pname, sizeof pname, "conv_h3u_kernel<%d>", mrep);
+    // algorithmic bytes: the fp32 sources read once (the upsampled branch at half resolution), the result written once
+    prof_begin(st, pname, 2.0 * posn * a.Cout * kch * 5.0, 4.0 * posn * (a.Cout + a.C0 * 0.5 + a.C1));
+    const int rc = wunet_launch_conv_h3u(a, mrep, dim3((unsigned)gx), smem, st);
+    prof_end(st);
+    if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3u kernel for mrep=%d (rc %d)", mrep, rc);
+    return 0;
+}
+
 // wgrad_h3d_kernel (DMA-staged) runs this layer's weight gradient: whole chunks inside one item (L >= 128), both buffers within
 // the 160 KB
 size_t h3w_dma_smem(const LayerPlan& l, int bf)

@@ -364,6 +364,17 @@ void layout_workspace(wunet_ctx* c)
                 l.d.ksplit = p.ksplit;
             }
             if (l.first) { l.f.ksplit = 1; l.f.grid_x = (int)(((long long)B * l.L + 1023) / 1024); }   // one statistics row per wave
+            // conv_h3u_kernel (wunet_h3u.h: the operand pass inside the conv, loader waves beside the MFMA waves) for the decoder levels
+            // whose conv is bound by operand bytes, not by the matrix pipe.  WUNET_H3U = "<eval min L>,<train min L>" (0: off), read
+            // when the context is planned
+            {
+                int u_eval = 2048, u_train = 0;
+                if (const char* e = getenv("WUNET_H3U")) sscanf(e, "%d,%d", &u_eval, &u_train);
+                const bool can = l.h3f && l.h3x && l.kind == LK_UPCAT && l.taps == 5 && l.L >= 256 && l.c0 % 8 == 0 && l.cin % 8 == 0 &&
+                                 l.h3f_mrep <= 3 && l.f.ksplit == 1 && !c->bf && !c->padded;
+                l.h3u = (can && u_eval > 0 && l.L >= u_eval) ? 1 : 0;
+                l.h3u_train = (can && u_train > 0 && l.L >= u_train) ? 1 : 0;
+            }
         }
         l.f_rows = l.h3f ? l.f.grid_x : l.f.grid_x * WUNET_WAVES;
         l.f_wpk = wpk;
