@@ -69,3 +69,17 @@ def test_torch_extension_is_optional_and_exposes_the_three_calls():
         # a CPU tensor is refused by the extension with the product path's message, before anything is enqueued
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             ext.adam_step([torch.zeros(3)], [torch.zeros(3)], [torch.zeros(3)], [torch.zeros(3)], 1e-3, 0.9, 0.999, 1e-8, 1, 1.0, None, None)
+
+
+def test_loader_prefetch_registers_are_untouched_until_their_wait():
+    """conv_h3u_kernel's loader waves prefetch from inline asm and order the use of the loaded registers with hand-placed waits (wunet_h3u.h):
+    tools/check_h3u_isa.py compiles the kernel to gfx950 ISA (hipcc cross-compiles here) and proves for this build that no instruction
+    touches a prefetch destination between its load and the wait that covers it."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    import os
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_h3u_isa.py")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "2 kernels checked, 0 problems" in p.stdout, p.stdout[-2000:] + p.stderr[-500:]

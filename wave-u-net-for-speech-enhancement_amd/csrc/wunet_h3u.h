@@ -58,6 +58,7 @@ __device__ __forceinline__ void wunet_loader_barrier(int younger)
     if (younger >= 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (younger == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    wunet_sched_fence();
 #endif
 }
 
@@ -81,6 +82,41 @@ __device__ __forceinline__ wunet_f4 wunet_ld4u(const float* p)
 #else
     typedef float wunet_f4u __attribute__((ext_vector_type(4), aligned(4)));
     return *reinterpret_cast<const wunet_f4u*>(p);
+#endif
+}
+
+// The prefetch loads are issued from inline asm: hipcc then neither counts them (its own wait-count bookkeeping put the first use of a tile
+// loaded two stages ago behind a wait for the loads issued a moment before - and a wait in front of every re-use of a register it believed
+// in flight) nor may it touch their destination registers before the loader's own wait (wunet_h3u_wait_tile): the values are asm outputs
+// the compiler believes defined, so nothing but the hand-placed s_waitcnt orders their use.  (Checked in the ISA of each build: no
+// compiler-inserted move reads these registers between the load and the wait.)
+__device__ __forceinline__ wunet_f4 wunet_ld4u_async(const float* p)
+{
+#ifdef WUNET_EMU
+    return wunet_ld4(p);
+#else
+    wunet_f4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#endif
+}
+__device__ __forceinline__ float wunet_ld1_async(const float* p)
+{
+#ifdef WUNET_EMU
+    return *p;
+#else
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+#endif
+}
+// at most N memory operations of this wave are still outstanding (they return in order: everything older has landed)
+template <int N>
+__device__ __forceinline__ void wunet_vm_wait()
+{
+#ifndef WUNET_EMU
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    wunet_sched_fence();            // (register-only arithmetic on the loaded values must not be scheduled above the wait: the compiler sees no dependency)
 #endif
 }
 
@@ -108,9 +144,9 @@ __device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw
     const float* const zq = zrow + (up ? wb : pc);
     const int m0 = up ? i0 : (in_m ? p_m : 0), m1 = up ? i1 : m0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) R.q[e] = wunet_ld4u(zq + (size_t)e * rs);
-    R.ma = zrow[(size_t)e_m * rs + m0];
-    R.mb = zrow[(size_t)e_m * rs + m1];
+    for (int e = 0; e < 8; ++e) R.q[e] = wunet_ld4u_async(zq + (size_t)e * rs);
+    R.ma = wunet_ld1_async(zrow + (size_t)e_m * rs + m0);
+    R.mb = wunet_ld1_async(zrow + (size_t)e_m * rs + m1);
     return 10;
 }
 
@@ -192,8 +228,10 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
         }
         const int col = 4 * lane + 6 + j;
         const int pw = (cw * COLS + (col & 3) * Q4 + (col >> 2)) * 8;
+        if (!(WUNET_H3U_ABL & 128) || h[0] == (wunet_half)0x1234) {      // (ablation 128: the arithmetic stays, the LDS writes go)
         wunet_sth8(xs + pw, h);
         wunet_sth8(xs + 4 * COLS * 8 + pw, l);
+        }
         // (training) the tile's own 256 samples of the operand also go to HBM, once per tile: the weight gradient reads them
         if (write_out && col >= 8 && col < 264) {
             const size_t o = (((size_t)T.b * A.C8 + c8) * L + (size_t)(P + j)) * 8;
@@ -304,6 +342,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
             wunet_h3u_issue(A, R1, t1, cw, lane);
             WUNET_H3U_DMA_W(t0, 0)
             wunet_h3u_issue(A, R2, t2, cw, lane);
+            wunet_vm_wait<0>();
             wunet_h3u_convert(A, R0, t0, xs0, cw, lane, xs_, coef);
         }
         // stage t (< T - 1): CUR_ holds the loads of tile t + 1, FREE_ (tile t's, converted a stage ago) takes those of tile t + 3; 10 loads
@@ -315,6 +354,9 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         WUNET_H3U_DMA_W(tn, (t + 1) & 1)                                                                           \
         WUNET_H3U_TILE(t + 3 < T ? t + 3 : T - 1, tnn)                                                             \
         wunet_h3u_issue(A, FREE_, tnn, cw, lane);                                                                  \
+        /* tile t + 1's loads have landed: younger than them are the loads of tiles t + 2 and t + 3 (20) and the DMA pieces of two  \
+           stages (>= 2 M_REP + 1 per wave and stage); with the operand's copy to HBM in the queue as well (training) everything */  \
+        if (A.oxh) wunet_vm_wait<0>(); else wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                              \
         wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, xs_, coef);                         \
         if (want_stats && (t + 1) % A.NS == 0) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                 \
         ++t;                                                                                                       \
