@@ -36,6 +36,7 @@ struct ConvH3uArgs {
     const float* ev_a; const float* ev_s; float* xrows;    // eval mode: this layer's BatchNorm scale / shift, its xb slot (see ConvH3Args)
     wunet_half* oxh; wunet_half* oxl;                      // nullptr, or the split operand [B][C8][L][8] written out as well (training: the weight gradient reads it)
     int B, Cout, L, logL, NS, ntiles, mblocks;
+    unsigned long long* trace;                             // nullptr, or (measurement builds, -DWUNET_H3U_TRACE) clock stamps of the stages, tools/h3u_trace.py
 };
 
 // (the helpers of the elementwise operand pass - wunet_x_scale, wunet_split_rt - live in wunet_h3_elem.h, which the host translation
@@ -151,8 +152,14 @@ __device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw
 }
 
 __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
-                                                  int lane, float xscale, const float* coef)
+                                                  int lane, float xscale, const float* coef, unsigned long long* tr = nullptr)
 {
+#ifdef WUNET_H3U_TRACE
+#define WUNET_H3U_SUB(K_) if (tr && cw == 0 && lane == 0) tr[K_] = wunet_memtime();
+#else
+#define WUNET_H3U_SUB(K_)
+#endif
+    WUNET_H3U_SUB(0)
     constexpr int COLS = 272, Q4 = COLS / 4;
     if (WUNET_H3U_ABL & 16) return;
     if (WUNET_H3U_ABL & 64) {                       // the loads stay alive (their registers are summed), nothing else of the conversion
@@ -174,6 +181,7 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
 #pragma unroll
         for (int e = 0; e < 8; ++e) { av[e] = coef[cc + e]; sv[e] = coef[A.C8 * 8 + cc + e]; }
     }
+    WUNET_H3U_SUB(1)
     // Rows are whole (Lt == L: the planner keeps padded lengths off this kernel), so the only lane whose window was clamped is the one
     // at the start of a row (P = -2: its loads started two elements later): `edge`.  No branch, no second code path: a few selects.
     const int P = T.l0 - 2 + 4 * lane;
@@ -213,6 +221,7 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
             vals[3][e] = edge ? u[1] : u[3];
         }
     }
+    WUNET_H3U_SUB(2)
     bool inside[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) inside[j] = !none && !(edge && j < 2);      // samples -2, -1: the conv's zero padding
@@ -239,6 +248,7 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
             wunet_sth8(A.oxl + o, l);
         }
     }
+    WUNET_H3U_SUB(3)
     // columns 262 .. 265 (samples l0 + 254 .. 257): channel lane >> 2, sample lane & 3 of lanes 0 .. 31, two bytes per plane each
     if (lane < 32) {
         const int e_m = lane >> 2, p_m = T.l0 + 254 + (lane & 3);
@@ -267,6 +277,18 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
         }
     }
 }
+
+// (-DWUNET_H3U_TRACE, tools/h3u_trace.py: lane 0 of MFMA wave 0 / loader wave 0 stamps its arrival at and its release from every stage
+//  barrier - trace[((block * 2 + role) * 128 + stage) * 2 + {0, 1}] - and the loader four points inside its conversion)
+#ifdef WUNET_H3U_TRACE
+#define WUNET_H3U_SUBPTR (A.trace && t < 128 ? A.trace + 256 * 2 * 128 * 2 + ((size_t)blockIdx.x * 128 + t) * 4 : nullptr)
+#define WUNET_H3U_STAMP(ROLE_, STAGE_, WHICH_)                                                                     \
+    if (A.trace && cw == 0 && lane == 0 && (STAGE_) < 128)                                                         \
+        A.trace[(((size_t)blockIdx.x * 2 + (ROLE_)) * 128 + (STAGE_)) * 2 + (WHICH_)] = wunet_memtime();
+#else
+#define WUNET_H3U_SUBPTR nullptr
+#define WUNET_H3U_STAMP(ROLE_, STAGE_, WHICH_)
+#endif
 
 template <int M_REP>
 __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uArgs A)
@@ -349,7 +371,9 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         // (tile t + 3's) are younger than the stage's last DMA piece at the next barrier
 #define WUNET_H3U_LOADER_STAGE(CUR_, FREE_)                                                                        \
     {                                                                                                              \
+        WUNET_H3U_STAMP(1, t, 0)                                                                                   \
         wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                                                        \
+        WUNET_H3U_STAMP(1, t, 1)                                                                                   \
         WUNET_H3U_TILE(t + 1, tn)                                                                                  \
         WUNET_H3U_DMA_W(tn, (t + 1) & 1)                                                                           \
         WUNET_H3U_TILE(t + 3 < T ? t + 3 : T - 1, tnn)                                                             \
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         /* tile t + 1's loads have landed: younger than them are the loads of tiles t + 2 and t + 3 (20) and the DMA pieces of two  \
            stages (>= 2 M_REP + 1 per wave and stage); with the operand's copy to HBM in the queue as well (training) everything */  \
         if (A.oxh) wunet_vm_wait<0>(); else wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                              \
-        wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, xs_, coef);                         \
+        wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, xs_, coef, WUNET_H3U_SUBPTR);       \
         if (want_stats && (t + 1) % A.NS == 0) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                 \
         ++t;                                                                                                       \
     }
@@ -394,7 +418,9 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = wunet_f4{0.f, 0.f, 0.f, 0.f};
         for (int st = 0; st < A.NS; ++st) {
+            WUNET_H3U_STAMP(0, k * A.NS + st, 0)
             wunet_wait_lds_barrier();
+            WUNET_H3U_STAMP(0, k * A.NS + st, 1)
             if (WUNET_H3U_ABL & 32) { par ^= 1; continue; }
             const wunet_half* const xs = xs0 + par * XP * 8;
             const wunet_half* const ws = ws0 + par * WP * 8;
