@@ -74,6 +74,7 @@ struct LayerPlan {
     size_t f_wpk, d_wpk; // float offsets inside the forward / backward weight packs
     // workspace (float offsets)
     size_t z, a, s, mean, rstd, xin, g, dx, k1, k2, k3;
+    size_t fin;          // cout "last arriver" counters of pass A (cleared by h3_scales_kernel at the head of every training forward)
     // fp16-split path
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;
