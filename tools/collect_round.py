@@ -17,7 +17,9 @@ for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.
                  ("conc_kernel_stats.csv", "bench_kernel_stats.csv"), ("serial_bench.json", "serial_bench.json"),
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
                  ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"), ("next_rows_bench.txt", "next_rows_bench.txt"),
-                 ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt")):
+                 ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt"),
+                 ("h3u_sweep.txt", "h3u_eval_threshold_sweep.txt"), ("h3u_ablation.txt", "h3u_ablation.txt"), ("h3u_stage_timeline.txt", "h3u_stage_timeline.txt"),
+                 ("pass_a_fin_ab.txt", "pass_a_fin_ab.txt"), ("git_state.txt", "git_state.txt")):
     if not os.path.exists(os.path.join(F, src)):
         continue
     if src.endswith(".json"):           # the bench line only (RCCL prints its banner into the same stream on some paths)

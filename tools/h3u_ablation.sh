@@ -1,10 +1,13 @@
 #!/bin/bash
 # What bounds conv_h3u_kernel: the kernel rebuilt with parts compiled out (-DWUNET_H3U_ABL=<bits>, wunet_h3u.h), the eval forward timed per variant.
+#   bits: 1 no prefetch loads   2 no conversion arithmetic   4 no MFMAs   8 no W DMA   16 no conversion at all (no LDS writes)   32 no fragment reads, no MFMAs
+#         64 the loads stay alive (their registers are summed) but nothing is converted   128 conversion without its LDS writes
+#   e.g. 100 = 64 + 32 + 4: the memory pipeline alone;  36: the loader waves alone;  16: the MFMA waves alone
 #   tools/h3u_ablation.sh build (container) -> tools/_lib_u<bits>.so ;  tools/h3u_ablation.sh run (GPU box) -> gpurun_out/h3u_ablation.txt
 set -e
 cd "$(dirname "$0")/.."
 CS=wave-u-net-for-speech-enhancement_amd/csrc
-VARIANTS=${VARIANTS:-"1 2 3 4 8 16 17 32 36 63"}
+VARIANTS=${VARIANTS:-"1 16 64 68 100 36 44 4"}
 if [ "$1" = build ]; then
     make -C $CS -j8 > /dev/null
     for a in $VARIANTS; do

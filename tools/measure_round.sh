@@ -11,7 +11,7 @@ if [ ! -f $R/tools/_git_state ] || [ "$(cut -d' ' -f3 $R/tools/_git_state)" != "
     echo "refused: tools/_git_state missing or not these sources - start the measurement with tools/run_measure_round.sh" >&2; exit 2
 fi
 cp $R/tools/_git_state $O/git_state.txt
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
     local name=$1; shift
@@ -75,6 +75,12 @@ python $R/tools/timeline.py $O/serial_kernel_trace.csv > $O/step_timeline.txt 2>
 cd $R
 { echo "tools/host_phases.py on one box, with the C++ marshalling extension (torch_ext/wunet_torch.cpp, the default when built) and with WUNET_NO_TORCH_EXT=1 (ctypes)"; timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu; WUNET_NO_TORCH_EXT=1 timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu | sed 's/^/ctypes: /'; } > $O/host_phases.txt
 timeout 300 python tools/next_rows_bench.py 2>/dev/null | grep -v amdgpu > $O/next_rows_bench.txt       # f1 / f3 / f4 of SURVEY.md section 8(f)
+# round 5: conv_h3u_kernel (eval decoder levels) - threshold sweep, ablation (tools/h3u_ablation.sh build first, in the container), stage timeline
+# (tools/build_h3u_trace.sh first); pass A's last-arriver BatchNorm-backward finalize against the separate launch
+timeout 300 bash tools/h3u_sweep.sh > $O/h3u_sweep.txt 2>&1
+ls tools/_lib_u16.so > /dev/null 2>&1 && H3U=8192,0 timeout 300 bash tools/h3u_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/h3u_ablation.txt $O/h3u_ablation.txt
+[ -f tools/_lib_trace.so ] && timeout 120 python tools/h3u_trace.py 2>/dev/null | grep -v amdgpu > $O/h3u_stage_timeline.txt
+timeout 300 bash tools/env_ab.sh WUNET_NO_PA_FIN > $O/pass_a_fin_ab.txt 2>&1
 ls tools/_lib_abl2.so > /dev/null 2>&1 && timeout 300 bash tools/conv_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/conv_ablation.txt $O/conv_ablation.txt
 [ -x tools/microbench/_dma_issue ] && timeout 60 tools/microbench/_dma_issue > $O/dma_issue_microbench.txt
 ls -la $O
