@@ -19,8 +19,11 @@ for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.
                  ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"), ("next_rows_bench.txt", "next_rows_bench.txt"),
                  ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt"),
                  ("h3u_sweep.txt", "h3u_eval_threshold_sweep.txt"), ("h3u_ablation.txt", "h3u_ablation.txt"), ("h3u_stage_timeline.txt", "h3u_stage_timeline.txt"),
-                 ("pass_a_fin_ab.txt", "pass_a_fin_ab.txt"), ("git_state.txt", "git_state.txt")):
+                 ("pass_a_fin_ab.txt", "pass_a_fin_ab.txt"), ("git_state.txt", "git_state.txt"), ("clock_state_probe.txt", "clock_state_probe.txt")):
     if not os.path.exists(os.path.join(F, src)):
+        continue
+    stamp = os.path.join(F, "git_state.txt")        # (gpurun merges into gpurun_out/ without deleting: leftovers of an earlier round are older than this run's stamp)
+    if os.path.exists(stamp) and os.path.getmtime(os.path.join(F, src)) < os.path.getmtime(stamp) - 5:
         continue
     if src.endswith(".json"):           # the bench line only (RCCL prints its banner into the same stream on some paths)
         lines = [ln for ln in open(os.path.join(F, src)).read().splitlines() if ln.startswith("{")]
