@@ -11,6 +11,10 @@ if [ ! -f $R/tools/_git_state ] || [ "$(cut -d' ' -f3 $R/tools/_git_state)" != "
     echo "refused: tools/_git_state missing or not these sources - start the measurement with tools/run_measure_round.sh" >&2; exit 2
 fi
 cp $R/tools/_git_state $O/git_state.txt
+# (a box that starts in the slow clock state - see wait_normal below - stays there for the whole call: give it back at once, the caller retries)
+ms0=$(cd $R && timeout 120 python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 5 2>/dev/null | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
+echo "$(date +%H:%M:%S) probe at the start of the call: training step $ms0 ms" > $O/clock_state_probe.txt
+if ! python -c "import sys; sys.exit(0 if float('$ms0') < 5.8 else 1)"; then echo "box in the slow clock state ($ms0 ms per step): nothing measured"; exit 3; fi
 TAG=${TAG:-r5}
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
@@ -56,7 +60,7 @@ cd $R
 # training step 7.0 ms instead of 5.1 - 5.3, every kernel alike, then back to normal within the same call): probe with a short run and wait
 # for the normal state before the timing runs (the probe's readings are kept in clock_state_probe.txt).
 wait_normal() {
-    for k in 1 2 3 4 5 6 7 8 9 10 11 12; do
+    for k in 1 2 3; do
         ms=$(timeout 120 python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 5 2>/dev/null | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
         echo "$(date +%H:%M:%S) probe before $1: training step $ms ms" >> $O/clock_state_probe.txt
         python -c "import sys; sys.exit(0 if float('$ms') < 5.8 else 1)" && return 0
