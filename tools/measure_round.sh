@@ -14,7 +14,8 @@ cp $R/tools/_git_state $O/git_state.txt
 # (a box that starts in the slow clock state - see wait_normal below - stays there for the whole call: give it back at once, the caller retries)
 ms0=$(cd $R && timeout 120 python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 5 2>/dev/null | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
 echo "$(date +%H:%M:%S) probe at the start of the call: training step $ms0 ms" > $O/clock_state_probe.txt
-if ! python -c "import sys; sys.exit(0 if float('$ms0') < 5.8 else 1)"; then echo "box in the slow clock state ($ms0 ms per step): nothing measured"; exit 3; fi
+# PMC_ONLY=1: the counter passes alone (bytes do not depend on the clock state: any box will do) - the stamp of profiles/pmc_traffic.json
+if [ -z "$PMC_ONLY" ] && ! python -c "import sys; sys.exit(0 if float('$ms0') < 5.8 else 1)"; then echo "box in the slow clock state ($ms0 ms per step): nothing measured"; exit 3; fi
 TAG=${TAG:-r5}
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
@@ -45,6 +46,7 @@ pmc_pass gemm_fp32 --gemm fp32
 pmc_pass deep16_bf16 --gemm bf16 --layers 16 --frame 65536 --batch 32
 pmc_pass eval_forward --mode forward
 cd $R; python tools/collect_round.py $TAG --pmc-only
+[ -n "$PMC_ONLY" ] && exit 0
 # SQ / GRBM counters of the serial step (one stream: kernels do not overlap, so counters and durations belong to one kernel)
 cd /tmp
 WUNET_NO_SIDE_STREAM=1 WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-trace \
