@@ -315,3 +315,38 @@ def test_fused_operand_conv_matches_the_two_kernel_path(monkeypatch, n, ci, B, T
         scale = max(np.abs(r).max(), 1e-6)
         assert np.abs(g_new[k] - r).max() < 3e-4 * scale + 1e-6, (k, np.abs(g_new[k] - r).max(), scale)
         assert np.abs(g_new[k] - g_old[k]).max() < 1e-4 * scale + 1e-7, k
+
+
+@pytest.mark.parametrize("n,ci,B,T,grid", [(3, 24, 2, 2048, ""), (4, 16, 3, 4096, "8"), (3, 20, 2, 1024, "")])
+def test_eval_encoder_conv_writes_the_next_operand(monkeypatch, n, ci, B, T, grid):
+    """Eval mode (enhancement.py:43,65-66): the BatchNorm coefficients are known before the chain starts, so an encoder level's conv
+    (conv_h3d_kernel<.., EVOP>) applies them, LeakyReLU and the `[:, :, ::2]` of unet_basic.py:86 in its epilogue and writes the next
+    level's split operand itself - scaled by a rigorous bound of its activation (absolute weight row sums x the measured maximum of its
+    input), since the measured maximum only exists when the launch ends.  Against the oracle and against the two-kernel path
+    (WUNET_NO_EVOP=1: prep_h3_kernel<0> + the measured scale); channel counts that are no multiple of 8; persistent blocks walking
+    several tiles; a second forward on the cached weight packs (and row sums) gives the same bits."""
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")
+    if grid:
+        monkeypatch.setenv("WUNET_H3_GRID", grid)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    sd = plan.golden_state(n, ci, 0)
+    ref = c_oracle.step(sd, noisy, clean, n, ci, False, "mse", want_grads=False, precision="f64")["out"]
+
+    def run(no_evop):
+        if no_evop:
+            monkeypatch.setenv("WUNET_NO_EVOP", "1")
+        else:
+            monkeypatch.delenv("WUNET_NO_EVOP", raising=False)
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
+        m, _, _ = _build(n, ci, eng)
+        m.eval()
+        with torch.no_grad():
+            return m(torch.from_numpy(noisy)).numpy(), m(torch.from_numpy(noisy)).numpy()
+
+    old, _ = run(True)
+    new, again = run(False)
+    assert np.abs(new - ref).max() < 2e-6 and np.abs(new - old).max() < 1e-6
+    assert not np.array_equal(new, old)             # (another scale, another rounding of the lo halves: really the other path)
+    assert np.array_equal(new, again)

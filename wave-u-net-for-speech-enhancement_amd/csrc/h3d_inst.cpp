@@ -15,8 +15,19 @@
         return 0;                                                                                          \
     }
 
-int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf)
+// EVOP: the eval-mode encoder form that also writes the next layer's operand (15 taps, whole-row tiles, two planes)
+#define WUNET_XCASE_EVOP(M)                                                                                \
+    if (evop && taps == 15 && mrep == M && nseg == 1 && !bf) {                                             \
+        if (!WUNET_H3D_HAS_TAIL(M, 1) && a.NFS != a.NS) return -3;                                         \
+        if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<15, M, 1, false, true>), smem) != 0) return -2;           \
+        WUNET_LAUNCH((conv_h3d_kernel<15, M, 1, false, true>), grid, dim3(WUNET_THREADS), smem, st, a);    \
+        return 0;                                                                                          \
+    }
+
+int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool evop)
 {
+    WUNET_XCASE_EVOP(2) WUNET_XCASE_EVOP(3) WUNET_XCASE_EVOP(4)
+    if (evop) return -4;
     WUNET_XCASE(15, 2, 1) WUNET_XCASE(15, 3, 1) WUNET_XCASE(15, 4, 1)
     WUNET_XCASE(5, 2, 1) WUNET_XCASE(5, 3, 1) WUNET_XCASE(5, 4, 1)
     WUNET_XCASE(15, 2, 2) WUNET_XCASE(15, 3, 2) WUNET_XCASE(5, 2, 2) WUNET_XCASE(5, 3, 2)

@@ -110,6 +110,20 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             WUNET_LAUNCH(pack_h3_kernel, dim3(pack_gx(), nd), dim3(WUNET_THREADS), 0, pst, tab);
             WUNET_CHECK_LAUNCH();
         }
+        if (!training) {
+            RowL1Table rt{};
+            int nr = 0;
+            for (int i = 0; i < c->NL; ++i) {
+                const LayerPlan& l = c->ly[i];
+                if (!l.evop) continue;
+                RowL1Desc& d = rt.d[nr++];
+                d.w = params[4 * i]; d.dst = ws + l.wl1; d.rows = l.cout; d.rowlen = l.cin * l.taps;
+            }
+            if (nr > 0) {
+                WUNET_LAUNCH(w_rowl1_kernel, dim3(8, nr), dim3(WUNET_THREADS), 0, pst, rt);
+                WUNET_CHECK_LAUNCH();
+            }
+        }
     }
     if (fside) {
         if (hipEventRecord(fside->ev_fpack, pst) != hipSuccess) return fail(WUNET_E_RUNTIME, "recording the pack event failed");
@@ -166,7 +180,9 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         const float* xin = noisy;
         // conv_h3u_kernel builds its operand itself (wunet_h3u.h): no operand pass for this layer
         const bool use_u = i > 0 && (training ? l.h3u_train : l.h3u);
-        if (i > 0 && !use_u) {
+        // eval mode: the producing encoder conv wrote this layer's operand in its epilogue (conv_h3d_kernel<.., EVOP>)
+        const bool op_by_producer = !training && i > 0 && l.kind == LK_DECIM && c->ly[l.src0].evop;
+        if (i > 0 && !use_u && !op_by_producer) {
             const LayerPlan& p = c->ly[l.src0];
             PrepArgs pa{};
             pa.z0 = ws + p.z; pa.a0 = ws + p.a; pa.s0 = ws + p.s; pa.x = ws + l.xin;
@@ -293,11 +309,20 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                              l.kind == LK_UPCAT ? fslot + (size_t)WUNET_SLOT_FLOATS * l.src1 + 4 : nullptr, sl, c->B, l.cin, l.L, st, c->bf);
                 WUNET_CHECK_LAUNCH();
             }
+            ConvH3OpOut opo{};
+            const bool evop = !training && l.evop && ev_epi;
+            if (evop) {
+                const LayerPlan& nx = c->ly[i + 1];
+                opo.h = reinterpret_cast<wunet_half*>(ws + nx.xh); opo.l = reinterpret_cast<wunet_half*>(ws + nx.xl);
+                opo.wl1 = ws + l.wl1; opo.xmax = fslot + (size_t)WUNET_SLOT_FLOATS * l.src0 + 4;
+                opo.xsc = fslot + (size_t)WUNET_SLOT_FLOATS * (i + 1); opo.C8 = (nx.cin + 7) / 8;
+            }
             int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, l.h3f_sps, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
-                                    l.cin, l.h3f_nch, l.L, st, ws + l.xzp, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf, l.h3f_ntt);
+                                    l.cin, l.h3f_nch, l.L, st, ws + l.xzp, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf, l.h3f_ntt,
+                                    evop ? &opo : nullptr);
             if (rc) return rc;
         } else if (tiny) {
             const size_t no = (size_t)c->B * l.cout * l.L;

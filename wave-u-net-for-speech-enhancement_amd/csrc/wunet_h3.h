@@ -52,6 +52,16 @@ struct ConvH3Args {
     int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
     size_t split_stride;                          // floats between the partial results of two splits
+    // EVOP (eval mode, an encoder level whose consumer is the next encoder level; conv_h3d_kernel<.., EVOP = true>): the epilogue also
+    // writes the NEXT layer's split operand - LeakyReLU(a z + s) at the even samples, scaled, hi / lo - into op_h / op_l
+    // [B][op_C8][L/2][8]: prep_h3_kernel<0> disappears for that layer.  Its power-of-two scale cannot wait for the layer's measured
+    // maximum (that exists when the launch ends), so it derives from a RIGOROUS bound every block computes for itself before its first
+    // tile: max_c |a_c| (||W_c||_1 xmax + |bias_c|) + |s_c| with xmax = the measured maximum of THIS layer's input (op_xmax) and
+    // ||W_c||_1 the absolute row sums of the weights (op_wl1) - loose by 2^4 .. 2^6 against the measured maximum, which costs nothing: a
+    // split value's error floor is 2^-25 in scaled units against maxima of 2^7 or more.  Block 0 publishes {scale, 1/scale} (op_xsc).
+    wunet_half* op_h; wunet_half* op_l;
+    const float* op_wl1; const float* op_xmax; float* op_xsc;
+    int op_C8;
 };
 
 // ---------------------------------------------------------------------------- weight gradient

@@ -65,6 +65,28 @@ static __global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTa
     }
 }
 
+// eval mode: absolute row sums ||W_c||_1 of the conv weights of the layers whose epilogue scales the next operand by a rigorous bound
+// (ConvH3Args::op_wl1; built with the weight packs, reused with them).  grid (8, layers): block (x, layer) the rows x, x + 8, ...
+struct RowL1Desc { const float* w; float* dst; int rows, rowlen; };
+struct RowL1Table { RowL1Desc d[WUNET_MAX_CONV_LAYERS]; };
+static __global__ __launch_bounds__(WUNET_THREADS) void w_rowl1_kernel(RowL1Table T)
+{
+    __shared__ float red[WUNET_WAVES];
+    const RowL1Desc& d = T.d[blockIdx.y];
+    for (int r = blockIdx.x; r < d.rows; r += gridDim.x) {
+        const float* wr = d.w + (size_t)r * d.rowlen;
+        float m = 0.0f;
+        for (int i = threadIdx.x; i < d.rowlen; i += WUNET_THREADS) m += fabsf(wr[i]);
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) m += wunet_shfl_xor(m, k);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        // (an upper bound is what is needed: rounding of the sum is covered by the factor 4 of head room above every operand bound)
+        if (threadIdx.x == 0) d.dst[r] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
 // eval mode with reused weight packs (WUNET_FWD_PACKS_VALID): what h3_scales_kernel does beside the weight maxima - the activation
 // bounds cleared (the conv epilogues / act_max_kernel fold this call's maxima into them), the DMA zero pads rewritten.  One block.
 static __global__ __launch_bounds__(WUNET_THREADS) void h3_slots_clear_kernel(ScaleTable T, int nl)

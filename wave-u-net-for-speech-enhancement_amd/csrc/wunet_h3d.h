@@ -29,7 +29,7 @@
 
 // (no tail stages in the two shapes at the register limit: they would spill)
 #define WUNET_H3D_HAS_TAIL(M_REP_, NSEG_) ((M_REP_) < 4 && (NSEG_) < 16)
-template <int TAPS, int M_REP, int NSEG, bool BF = false>
+template <int TAPS, int M_REP, int NSEG, bool BF = false, bool EVOP = false>
 __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A)
 {
     constexpr int PAD = TAPS / 2;
@@ -168,6 +168,21 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     constexpr int NTT = (TAPS + 3) / 4;            // steps of a tail stage
     int stamp = 0;
     float amax_run = 0.0f;                          // eval mode: the block's running maximum of the activation bound over its work items
+    float op_scale = 1.0f;                          // EVOP: scale of the consumer's operand (ConvH3Args: from the rigorous bound of this layer's activation)
+    if (EVOP) {
+        const float xm = A.op_xmax[0];
+        float m = 0.0f;
+        for (int c = tid; c < A.Cout; c += WUNET_THREADS)
+            m = fmaxf(m, fabsf(A.ev_a[c]) * (A.op_wl1[c] * xm + (A.bias ? fabsf(A.bias[c]) : 0.0f)) + fabsf(A.ev_s[c]));
+#pragma unroll
+        for (int k = 1; k < 64; k <<= 1) m = fmaxf(m, wunet_shfl_xor(m, k));
+        if (lane == 0) red[wave] = m;
+        wunet_wait_lds_barrier();
+        float inv_;
+        wunet_pow2_scale(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), op_scale, inv_);
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { A.op_xsc[0] = op_scale; A.op_xsc[1] = inv_; }
+        wunet_wait_lds_barrier();                     // (red is the epilogue's hand-over area)
+    }
     WUNET_H3D_STAMP(stamp) ++stamp;
     if (st_beg < nstage) {
         WUNET_H3D_ISSUE_X(b, l0, (!KT || st_beg < nfs ? st_beg / NTG : tch))
@@ -320,6 +335,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     }                                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};                                         \
+        float ye[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   /* EVOP: the activation at the lane's two even samples, rows r */ \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                           \
             const int co = (mt0 + mt) * 16 + q * 4 + r;                                                           \
             const float bv = bvs[mt][r];                                                                          \
@@ -334,6 +350,19 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
                 if (EVAL_) {                                                                                      \
                     const float ea = eas[mt][r], es = ess[mt][r];                                                 \
                     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) amax = fmaxf(amax, fabsf(ea * o[nt] + es));  \
+                    if (EVOP) { ye[0][r] = wunet_lrelu(ea * o[0] + es); ye[1][r] = wunet_lrelu(ea * o[2] + es); } \
+                }                                                                                                 \
+            }                                                                                                     \
+        }                                                                                                         \
+        if (EVOP && (EVAL_)) {         /* rows q*4 .. q*4+3 = half of the 16-byte piece of channel group 2 (mt0 + mt) + (q >> 1) */ \
+            const int c8o = (mt0 + mt) * 2 + (q >> 1);                                                            \
+            if (c8o < A.op_C8 && bo < A.B) {                                                                      \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                   \
+                    wunet_half hh[4], ll[4];                                                                      \
+                    _Pragma("unroll") for (int r = 0; r < 4; ++r) wunet_split_h(op_scale * ye[j][r], hh[r], ll[r]); \
+                    const size_t oo = ((((size_t)bo * A.op_C8 + c8o) << (A.logL - 1)) + (size_t)(((l0 + ll0) >> 1) + j)) * 8 + (q & 1) * 4; \
+                    wunet_sth4(A.op_h + oo, hh);                                                                  \
+                    wunet_sth4(A.op_l + oo, ll);                                                                  \
                 }                                                                                                 \
             }                                                                                                     \
         }                                                                                                         \

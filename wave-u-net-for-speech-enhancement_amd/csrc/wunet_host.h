@@ -74,6 +74,8 @@ struct LayerPlan {
     size_t f_wpk, d_wpk; // float offsets inside the forward / backward weight packs
     // workspace (float offsets)
     size_t z, a, s, mean, rstd, xin, g, dx, k1, k2, k3;
+    size_t wl1;          // cout absolute row sums of the conv weight (eval mode: the bound conv_h3d_kernel<.., EVOP> scales the next operand by)
+    int evop;            // eval mode: this encoder layer's conv also writes the next layer's operand (no prep_h3_kernel<0> for that one)
     size_t fin;          // cout "last arriver" counters of pass A (cleared by h3_scales_kernel at the head of every training forward)
     // fp16-split path
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
@@ -136,10 +138,12 @@ namespace wunet_host {
 void layout_workspace(wunet_ctx* c);
 int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc, const float* xb0, const float* xb1, float* xsc,
                  int B, int C, int L, hipStream_t st, int bf = 0);
+// (op: eval mode, the conv also writes the next encoder layer's operand - ConvH3Args::op_*, conv_h3d_kernel<.., EVOP>)
+struct ConvH3OpOut { wunet_half* h; wunet_half* l; const float* wl1; const float* xmax; float* xsc; int C8; };
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a = nullptr, const float* ev_s = nullptr,
-                   float* xrows = nullptr, int bf = 0, int ntt = 0);
+                   float* xrows = nullptr, int bf = 0, int ntt = 0, const ConvH3OpOut* op = nullptr);
 int launch_conv_h3u(const ConvH3uArgs& a, int mrep, int mtiles_p, int kch, hipStream_t st);
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
                     const float* sc, const float* sc2, float* part, int B, hipStream_t st, int bf = 0);

@@ -110,7 +110,8 @@ int h3_grid_cap()
 }
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
-                   int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a, const float* ev_s, float* xrows, int bf, int ntt)
+                   int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a, const float* ev_s, float* xrows, int bf, int ntt,
+                   const ConvH3OpOut* op)
 {
     // conv_h3d_kernel addresses its DMA pieces as SGPR base + unsigned 32-bit offset: lo plane / lo pack behind the hi one, the zero pad
     // behind both, everything within 4 GiB of the hi arrays
@@ -124,6 +125,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     a.xh = xh; a.xl = xl; a.wh = wh; a.wl = wl; a.bias = bias; a.sc = sc; a.sc2 = sc2; a.out = out; a.stats = stats;
     a.B = B; a.Cout = rows; a.C8 = (kch + 7) / 8; a.NCH = nch; a.L = L; a.logL = ilog2(L);
     a.ev_a = ev_a; a.ev_s = ev_s; a.xrows = xrows;
+    if (op) { a.op_h = op->h; a.op_l = op->l; a.op_wl1 = op->wl1; a.op_xmax = op->xmax; a.op_xsc = op->xsc; a.op_C8 = op->C8; }
     a.xdelta = (unsigned)xd; a.wdelta = (unsigned)wd; a.zpad = zpad;
     const int nseg = L >= 256 ? 1 : 256 / L, nstage = h3_stage_count(kch, taps, ntt);
     a.NS = nstage; a.NFS = ntt ? (a.C8 / 4) * (taps / 5) : nstage;
@@ -133,8 +135,8 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     a.trace = g_h3_trace;
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
-    snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
-    prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)));
+    snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
+    prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)) + (op ? 2.0 * posn * rows : 0.0));
     const size_t smem = h3d_smem(nseg, mrep, bf);
     const int nitems = a.ntiles * a.mblocks;
     // resident blocks: two per CU, one for the 16-segment tile (96 KB); a K-split layer whose items x splits fit them runs one item per block
@@ -143,7 +145,8 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     if (gx < 8) gx = 8;
     if (gx > nitems) gx = nitems;
     const dim3 grid((unsigned)gx, (unsigned)ksplit);
-    const int rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0);
+    if (op && (ksplit != 1 || nseg != 1 || !ev_a || !xrows)) return fail(WUNET_E_ARG, "conv_h3d EVOP needs an un-split whole-row eval launch");
+    const int rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, op != nullptr);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d nseg=%d (rc %d)", taps, mrep, nseg, rc);
     return 0;

@@ -391,6 +391,7 @@ void layout_workspace(wunet_ctx* c)
         l.s = off; off += align64(l.cout);
         l.mean = off; off += align64(l.cout);
         l.rstd = off; off += align64(l.cout);
+        l.wl1 = off; off += align64(l.cout);
         l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
     }
     // the operand pass of encoder-side layer i (decimation of its producer's activation) also writes that activation at full
@@ -424,6 +425,16 @@ void layout_workspace(wunet_ctx* c)
     c->h3_wf_lo = off; off += align64((wfh + 1) / 2);
     c->fslot_off = off; off += align64((size_t)WUNET_SLOT_FLOATS * c->NL);
     c->wmax_off = off; off += align64((size_t)WUNET_WMAX_PARTS * c->NL);
+    // eval mode: an encoder level's un-split split conv (15 taps, whole-row tiles) writes the next encoder level's operand in its epilogue
+    // (conv_h3d_kernel<.., EVOP>; WUNET_NO_EVOP=1, read when the context is planned: A/B switch)
+    for (int i = 0; i < c->NL; ++i) c->ly[i].evop = 0;
+    for (int i = 1; i + 1 <= c->n; ++i) {
+        LayerPlan& p = c->ly[i];
+        const LayerPlan& q = c->ly[i + 1];
+        if (p.h3f && !p.first && p.taps == 15 && p.L >= 256 && p.f.ksplit == 1 && p.h3f_mrep <= 4 && q.kind == LK_DECIM && q.src0 == i && q.h3f && q.h3x &&
+            !c->bf && !c->padded && !getenv("WUNET_NO_EVOP"))
+            p.evop = 1;
+    }
     for (int i = 0; i < c->NL; ++i) c->ly[i].feeds_h3 = 0;
     for (int i = 1; i < c->NL; ++i) {
         const LayerPlan& l = c->ly[i];
