@@ -41,7 +41,9 @@ def lib_name(k):
     base, args = k.split("<", 1)
     a = [t.strip() for t in args.rstrip(">").split(",")]
     if base == "conv_h3d_kernel":
-        return "%s<%s, %s, %s%s>" % (base, a[0], a[1], a[2], ", bf16" if len(a) > 3 and a[3] == "true" else "")
+        return "%s<%s, %s, %s%s>" % (base, a[0], a[1], a[2], ", bf16" if len(a) > 3 and a[3] == "true" else ", evop" if len(a) > 4 and a[4] == "true" else "")
+    if base == "conv_h3u_kernel":
+        return "%s<%s>" % (base, a[0])
     if base == "wgrad_h3d_kernel":
         return "%s<%s, %s%s>" % (base, a[0], a[1], ", bf16" if a[3] == "true" else "")
     if base == "wgrad_h3_kernel":
