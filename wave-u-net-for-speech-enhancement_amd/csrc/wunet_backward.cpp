@@ -90,17 +90,6 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
             p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.Lt;
         }
-        // several blocks per channel: the BatchNorm-backward finalize is done by the block that arrives last at the channel's counter
-        // (pass_a_kernel's FIN; the counters are cleared by h3_scales_kernel, which only the split planner launches; WUNET_NO_PA_FIN=1: A/B
-        // switch, read once).  The levels whose finalize runs in the prologue of gz_split_h3_kernel's blocks keep that.
-        static const bool no_pa_fin = getenv("WUNET_NO_PA_FIN") != nullptr;
-        const bool fin_in_gz0 = i > 0 && l.h3d && l.a_split * l.cout <= WUNET_GZ_FIN_LOADS && l.cout <= WUNET_GZ_FIN_C;
-        const bool fin_in_a = !fuse && !tiny && !fin_in_gz0 && c->h3 && !no_pa_fin;
-        if (fin_in_a) {
-            p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
-            p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.Lt;
-            p.fin = reinterpret_cast<unsigned*>(ws + l.fin); p.bound = ws + c->bound_off;
-        }
         // the last layer on the split kernels: its g is recomputed from the head gradient by gz_split_h3_kernel (HEAD mode), not stored
         const bool head_in_gz = i == NL - 1 && i > 0 && l.h3d && !fuse && !tiny;
         // an encoder layer on the split kernels whose two data gradients are whole tensors: g is recomputed by gz_split_h3_kernel (ENC
@@ -151,7 +140,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             // (short levels on the split kernels: the finalize runs in the prologue of gz_split_h3_kernel's blocks instead -
             //  WUNET_NO_BWDFIN_FUSE=1: A/B switch)
             const bool fin_in_gz = i > 0 && l.h3d && l.a_split * l.cout <= WUNET_GZ_FIN_LOADS && l.cout <= WUNET_GZ_FIN_C;
-            if (!fin_in_gz && !fin_in_a) {
+            if (!fin_in_gz) {
                 WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
                 WUNET_CHECK_LAUNCH();
             }

@@ -178,31 +178,6 @@ __device__ __forceinline__ unsigned long long wunet_memtime() { return __builtin
 __device__ __forceinline__ void wunet_opaque(int& v) { asm volatile("" : "+v"(v)); }
 #endif
 
-// ---- "last arriver" hand-over between the blocks of ONE launch (a reduction finished by whichever block comes last, instead of a
-// kernel of its own behind the launch): every block publishes its partial results (plain stores), then wunet_arrive() - a device-scope
-// release fence and a ticket from an atomic counter.  The block that draws the last ticket sees every other block's results behind its
-// acquire fence, finishes the reduction in a FIXED order (nothing depends on who arrives when) and hands the counter back as zero.
-// Call from ONE thread per block, behind a barrier that orders the block's result stores in front of it.
-#ifdef WUNET_EMU
-__device__ __forceinline__ bool wunet_arrive(unsigned* counter, unsigned expected)
-{
-    const unsigned t = __atomic_fetch_add(counter, 1u, __ATOMIC_SEQ_CST);
-    if (t + 1 != expected) return false;
-    *counter = 0;
-    return true;
-}
-#else
-__device__ __forceinline__ bool wunet_arrive(unsigned* counter, unsigned expected)
-{
-    __threadfence();
-    const unsigned t = atomicAdd(counter, 1u);
-    if (t + 1 != expected) return false;
-    __threadfence();
-    *counter = 0;                      // (the next launch that uses the counter starts from zero; stream order separates the launches)
-    return true;
-}
-#endif
-
 // hi/lo fp16 split of s*x (s a power of two chosen so that |s*x| stays far below 65504)
 __device__ __forceinline__ void wunet_split_h(float x, wunet_half& hi, wunet_half& lo)
 {

@@ -421,9 +421,6 @@ struct PassAArgs {
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
     const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
-    // FIN (levels of several blocks per channel): the block that arrives LAST at its channel's counter runs bn_finalize_bwd_kernel's
-    // reduction of the channel's partial rows (same order, same arithmetic: the same bits) - no launch of its own for it
-    unsigned* fin; float* bound;
 };
 
 template <int MODE, bool FUSE = false>
@@ -589,47 +586,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         __syncthreads();
         block_sum2(s3, dummy, red);
         if (threadIdx.x == 0) A.hpart[(size_t)by * A.C + c] = (float)s3;
-    }
-    if (A.fin) {
-        __shared__ int last_;
-        __syncthreads();                       // (thread 0's rows are written)
-        if (threadIdx.x == 0) last_ = wunet_arrive(A.fin + c, ny) ? 1 : 0;
-        __syncthreads();
-        if (last_) {
-            // bn_finalize_bwd_kernel for channel c, verbatim
-            const int tid = threadIdx.x, rows = (int)ny;
-            double t1 = 0.0, t2 = 0.0;
-            for (int r = tid; r < rows; r += WUNET_THREADS) {
-                const float* pr = A.part + ((size_t)r * A.C + c) * 2;
-                t1 += (double)pr[0];
-                t2 += (double)pr[1];
-            }
-            block_sum2(t1, t2, red);
-            if (tid == 0) {
-                A.dgamma[c] = (float)t2;
-                A.dbeta[c] = (float)t1;
-                A.dbias[c] = 0.0f;
-                const double m1 = t1 / A.count, m2 = t2 / A.count;
-                const double ar = (double)A.gamma[c] * (double)rstd;
-                A.k1[c] = (float)ar;
-                A.k2[c] = (float)(-ar * m2 * (double)rstd);
-                A.k3[c] = (float)(ar * m2 * (double)rstd * (double)mu - ar * m1);
-            }
-            if (A.pmax) {
-                float qg = 0.0f, qz = 0.0f;
-                for (int r = tid; r < rows; r += WUNET_THREADS) {
-                    const float* pm = A.pmax + ((size_t)r * A.C + c) * 2;
-                    qg = fmaxf(qg, pm[0]);
-                    qz = fmaxf(qz, pm[1]);
-                }
-                block_max2(qg, qz, red);
-                if (tid == 0) {
-                    const double m1 = t1 / A.count, m2 = t2 / A.count;
-                    const double ar = (double)A.gamma[c] * (double)rstd;
-                    A.bound[c] = (float)(fabs(ar) * (double)qg + fabs(ar * m2 * (double)rstd) * (double)qz + fabs(ar * m1));
-                }
-            }
-        }
     }
 }
 

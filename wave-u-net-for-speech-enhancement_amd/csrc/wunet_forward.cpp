@@ -82,11 +82,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
                 d.sqrtn = sqrtf((float)((double)c->B * l.Lt));
                 d.zp0 = l.h3f ? ws + l.xzp : nullptr;
                 d.zp1 = (l.h3d && training && save_for_backward) ? ws + l.gzp : nullptr;      // (the backward segment only exists then)
-                d.fin = (training && save_for_backward) ? reinterpret_cast<unsigned*>(ws + l.fin) : nullptr;
                 any = any || l.h3f;
             }
             T.wmax = ws + c->wmax_off; T.slots = ws + c->fslot_off; T.training = training ? 1 : 0;
-            if (any || (training && save_for_backward)) {       // (also clears the backward's last-arriver counters)
+            if (any) {
                 WUNET_LAUNCH(h3_scales_kernel, dim3(WUNET_WMAX_PARTS, c->NL), dim3(WUNET_THREADS), 0, pst, T);
                 WUNET_CHECK_LAUNCH();
             }

@@ -21,7 +21,6 @@ struct ScaleDesc {
     const float* gamma; const float* beta; int C; // BatchNorm affine parameters of the layer
     float sqrtn;                                  // sqrt(B * L)
     float* zp0; float* zp1;                       // nullptr or the 16-byte zero pads behind the layer's split conv input / split g_z: cleared here
-    unsigned* fin;                                // nullptr or the layer's C "last arriver" counters of the backward (wunet_arrive): cleared here
 };
 struct ScaleTable { ScaleDesc d[WUNET_MAX_CONV_LAYERS]; float* wmax; float* slots; int training; };
 
@@ -60,8 +59,6 @@ static __global__ __launch_bounds__(WUNET_THREADS) void h3_scales_kernel(ScaleTa
             if (d.zp0) d.zp0[tid] = 0.0f;
             if (d.zp1) d.zp1[tid] = 0.0f;
         }
-        if (d.fin)
-            for (int c = tid; c < d.C; c += WUNET_THREADS) d.fin[c] = 0u;
     }
 }
 

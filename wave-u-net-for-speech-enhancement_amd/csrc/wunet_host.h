@@ -76,7 +76,6 @@ struct LayerPlan {
     size_t z, a, s, mean, rstd, xin, g, dx, k1, k2, k3;
     size_t wl1;          // cout absolute row sums of the conv weight (eval mode: the bound conv_h3d_kernel<.., EVOP> scales the next operand by)
     int evop;            // eval mode: this encoder layer's conv also writes the next layer's operand (no prep_h3_kernel<0> for that one)
-    size_t fin;          // cout "last arriver" counters of pass A (cleared by h3_scales_kernel at the head of every training forward)
     // fp16-split path
     int h3f, h3d;                 // forward conv / data gradient use conv_h3_kernel
     int h3f_mrep, h3f_mtp, h3f_nch, h3d_mrep, h3d_mtp, h3d_nch;

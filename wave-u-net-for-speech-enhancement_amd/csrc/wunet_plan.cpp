@@ -456,7 +456,6 @@ void layout_workspace(wunet_ctx* c)
         l.k1 = off; off += align64(l.cout);
         l.k2 = off; off += align64(l.cout);
         l.k3 = off; off += align64(l.cout);
-        l.fin = off; off += align64(l.cout);
         l.d_wpk = wpkb;
         if (i > 0) wpkb += align64((size_t)l.d.mtiles_p * l.d.cp * l.taps * 16);
         if (l.h3w) plan_h3_wgrad(l, B);
