@@ -11,12 +11,6 @@ if [ ! -f $R/tools/_git_state ] || [ "$(cut -d' ' -f3 $R/tools/_git_state)" != "
     echo "refused: tools/_git_state missing or not these sources - start the measurement with tools/run_measure_round.sh" >&2; exit 2
 fi
 cp $R/tools/_git_state $O/git_state.txt
-# (a box that starts in the slow clock state - see wait_normal below - stays there for the whole call: give it back at once, the caller retries)
-ms0=$(cd $R && timeout 120 python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 5 2>/dev/null | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
-echo "$(date +%H:%M:%S) probe at the start of the call: training step $ms0 ms" > $O/clock_state_probe.txt
-# PMC_ONLY=1: the counter passes alone (bytes do not depend on the clock state: any box will do) - the stamp of profiles/pmc_traffic.json
-if [ -z "$PMC_ONLY" ] && ! python -c "import sys; sys.exit(0 if float('$ms0') < 5.8 else 1)"; then echo "box in the slow clock state ($ms0 ms per step): nothing measured"; exit 3; fi
-TAG=${TAG:-r5}
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
     local name=$1; shift
@@ -58,19 +52,6 @@ WUNET_NO_SIDE_STREAM=1 WUNET_BENCH_NO_MEDIAN=1 timeout 400 rocprofv3 --kernel-tr
 python $R/tools/pmc_sq.py $O/pmc_sq $O/pmc_grbm > $O/pmc_sq.txt 2> $O/pmc_sq.err
 rm -rf $O/pmc_sq $O/pmc_grbm
 cd $R
-# Some boxes of the pool run ~35 % slow for minutes at a time (seen behind the counter passes and, on other calls, from the first second:
-# training step 7.0 ms instead of 5.1 - 5.3, every kernel alike, then back to normal within the same call): probe with a short run and wait
-# for the normal state before the timing runs (the probe's readings are kept in clock_state_probe.txt).
-wait_normal() {
-    for k in 1 2 3; do
-        ms=$(timeout 120 python bench.py --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 5 2>/dev/null | python -c "import json,sys; print('%.3f' % json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])")
-        echo "$(date +%H:%M:%S) probe before $1: training step $ms ms" >> $O/clock_state_probe.txt
-        python -c "import sys; sys.exit(0 if float('$ms') < 5.8 else 1)" && return 0
-        sleep 20
-    done
-    return 0
-}
-wait_normal bench.json
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 600 $O/bench.json; echo
 WUNET_BENCH_ALL=1 timeout 200 python bench.py --no-cpu-baseline --no-extras > $O/bench_all_kernels.json 2>/dev/null
 python tools/traffic_table.py $O/bench_all_kernels.json > $O/traffic_by_family.txt 2>&1
@@ -82,7 +63,7 @@ timeout 200 python bench.py --graph on --no-cpu-baseline --no-extras --no-roofli
 timeout 200 python bench.py --graph off --no-cpu-baseline --no-extras --no-roofline --steps 100 > $O/bench_eager.json 2>/dev/null
 # (the training soak - three seeds, 100 / 300 / 600 steps, split against exact fp32 and the summation-order control - is profiles/r3_training_soak.txt,
 #  measured by its own calls: bench.py --seed S --steps N --warmup 0 [--gemm fp32] with WUNET_BENCH_NO_MEDIAN=1)
-cd $R; wait_normal rocprof-stats; cd /tmp
+cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/conc -o conc -- python $R/bench.py --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -o serial -- python $R/bench.py --no-cpu-baseline --no-extras > $O/serial_bench.json 2>/dev/null
 WUNET_NO_SIDE_STREAM=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/fwd -o fwd -- python $R/bench.py --mode forward --no-cpu-baseline --no-roofline > $O/forward_bench.json 2>/dev/null
@@ -95,11 +76,13 @@ cd $R
 { echo "tools/host_phases.py on one box, with the C++ marshalling extension (torch_ext/wunet_torch.cpp, the default when built) and with WUNET_NO_TORCH_EXT=1 (ctypes)"; timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu; WUNET_NO_TORCH_EXT=1 timeout 120 python tools/host_phases.py 2>/dev/null | grep -v amdgpu | sed 's/^/ctypes: /'; } > $O/host_phases.txt
 timeout 300 python tools/next_rows_bench.py 2>/dev/null | grep -v amdgpu > $O/next_rows_bench.txt       # f1 / f3 / f4 of SURVEY.md section 8(f)
 # round 5: conv_h3u_kernel (eval decoder levels) - threshold sweep, ablation (tools/h3u_ablation.sh build first, in the container), stage timeline
-# (tools/build_h3u_trace.sh first); pass A's last-arriver BatchNorm-backward finalize against the separate launch
+# (tools/build_h3u_trace.sh first); the previous round's library against this one on this box (tools/_lib_round4.so)
 timeout 300 bash tools/h3u_sweep.sh > $O/h3u_sweep.txt 2>&1
 ls tools/_lib_u16.so > /dev/null 2>&1 && H3U=8192,0 timeout 300 bash tools/h3u_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/h3u_ablation.txt $O/h3u_ablation.txt
 [ -f tools/_lib_trace.so ] && timeout 120 python tools/h3u_trace.py 2>/dev/null | grep -v amdgpu > $O/h3u_stage_timeline.txt
-timeout 300 bash tools/env_ab.sh WUNET_NO_PA_FIN > $O/pass_a_fin_ab.txt 2>&1
+[ -f tools/_lib_round4.so ] && timeout 400 bash tools/round_vs_round.sh > $O/round4_vs_round5_same_box.txt 2>&1
+{ for rep in 1 2; do for v in "" 1; do if [ -z "$v" ]; then unset WUNET_NO_EVOP; else export WUNET_NO_EVOP=1; fi
+    python bench.py --mode forward --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 10 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('WUNET_NO_EVOP=$v eval forward ms %.4f median %.4f' % (j['ms_per_step'], j['ms_per_step_median']))"; done; done; unset WUNET_NO_EVOP; } > $O/evop_ab.txt 2>&1
 ls tools/_lib_abl2.so > /dev/null 2>&1 && timeout 300 bash tools/conv_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/conv_ablation.txt $O/conv_ablation.txt
 [ -x tools/microbench/_dma_issue ] && timeout 60 tools/microbench/_dma_issue > $O/dma_issue_microbench.txt
 ls -la $O

@@ -15,6 +15,6 @@ if [ -n "$(git status --porcelain -- $PKG/csrc include bench.py tools/measure_ro
 fi
 python -c "import __graft_entry__ as g; g.build()" > /dev/null
 echo "$(git rev-parse HEAD) clean $(python -c 'import bench; print(bench.source_hash())')" > tools/_git_state
-# PMC_ONLY=1 tools/run_measure_round.sh: the counter passes alone (HBM bytes do not depend on the box's clock state) -> profiles/pmc_traffic.json
+# PMC_ONLY=1 tools/run_measure_round.sh: the counter passes alone -> profiles/pmc_traffic.json (40 s of GPU time: re-stamp after any change under csrc/)
 /usr/local/graft/bin/gpurun --timeout ${1:-2400} -- "TAG=$TAG PMC_ONLY=$PMC_ONLY bash tools/measure_round.sh"
 python tools/collect_round.py $TAG ${PMC_ONLY:+--pmc-only}
