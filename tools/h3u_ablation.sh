@@ -2,12 +2,14 @@
 # What bounds conv_h3u_kernel: the kernel rebuilt with parts compiled out (-DWUNET_H3U_ABL=<bits>, wunet_h3u.h), the eval forward timed per variant.
 #   bits: 1 no prefetch loads   2 no conversion arithmetic   4 no MFMAs   8 no W DMA   16 no conversion at all (no LDS writes)   32 no fragment reads, no MFMAs
 #         64 the loads stay alive (their registers are summed) but nothing is converted   128 conversion without its LDS writes
-#   e.g. 100 = 64 + 32 + 4: the memory pipeline alone;  36: the loader waves alone;  16: the MFMA waves alone
+#   e.g. 100 = 64 + 32 + 4: the memory pipeline alone;  36: the loader waves alone;  64: loads in flight but nothing converted (the MFMA waves + the memory pipeline)
+#   (16 WITHOUT 1 is not a valid build since the prefetch loads come from inline asm: with nothing reading their destination registers hipcc hands
+#    those registers to address arithmetic while the loads are in flight - a wild address sooner or later.  Use 64: it keeps the registers alive.)
 #   tools/h3u_ablation.sh build (container) -> tools/_lib_u<bits>.so ;  tools/h3u_ablation.sh run (GPU box) -> gpurun_out/h3u_ablation.txt
 set -e
 cd "$(dirname "$0")/.."
 CS=wave-u-net-for-speech-enhancement_amd/csrc
-VARIANTS=${VARIANTS:-"1 16 64 68 100 36 44 4"}
+VARIANTS=${VARIANTS:-"1 4 8 36 44 64 68 100"}
 if [ "$1" = build ]; then
     make -C $CS -j8 > /dev/null
     for a in $VARIANTS; do
