@@ -74,40 +74,79 @@ __device__ __forceinline__ void wunet_loader_barrier(int younger)
 // BatchNorm scale / shift, LeakyReLU, ATen's upsample weights, scale, split; LDS writes; in training also the operand's copy in HBM).
 struct WunetH3uRaw { wunet_f4 q[8]; float ma, mb; };
 struct WunetH3uTile { int b, l0, mt0, ch; };
-
-// 16 bytes from a 4-byte aligned address
-__device__ __forceinline__ wunet_f4 wunet_ld4u(const float* p)
+// Where a loader stands in the block's sequence of stages: chunk `ch` of the work item (position tile, row block mb).  Advanced stage by
+// stage with adds and compares: deriving it from the stage number costs two integer divisions per tile - with two tiles per stage ~90 of
+// the ~330 instructions a loader wave spent between the stage's barrier and its last prefetch load (a wave issues one instruction per
+// ~4.4 cycles whatever the unit: the loaders are ISSUE bound, profiles/r5_h3u_stage_timeline.txt).
+struct WunetH3uCursor { int ch, tile, mb; };
+struct WunetH3uStep { int NS, mblocks, qG, rG; };                 // G = qG * mblocks + rG: the next item of a block is G items further
+__device__ __forceinline__ void wunet_h3u_advance(WunetH3uCursor& c, const WunetH3uStep& S)
 {
-#ifdef WUNET_EMU
-    return wunet_ld4(p);
-#else
-    typedef float wunet_f4u __attribute__((ext_vector_type(4), aligned(4)));
-    return *reinterpret_cast<const wunet_f4u*>(p);
-#endif
+    if (++c.ch == S.NS) {
+        c.ch = 0; c.tile += S.qG; c.mb += S.rG;
+        if (c.mb >= S.mblocks) { c.mb -= S.mblocks; ++c.tile; }
+    }
+}
+// ATen's interpolation weights of the lane's four outputs P .. P+3 and of its value of the last 4 columns: they depend on the position
+// tile only, so they are computed once per work item (NS stages) and kept - not once per stage.
+struct WunetH3uCoord { float w0[4], w1[4], mw0, mw1; };
+__device__ __forceinline__ void wunet_h3u_coord(const ConvH3uArgs& A, int l0, int lane, WunetH3uCoord& K)
+{
+    const int Lth = A.Lt >> 1, P = l0 - 2 + 4 * lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int i0, i1;
+        wunet_up_coord(P + j < 0 ? 0 : P + j, Lth, A.up_scale, i0, i1, K.w0[j], K.w1[j]);
+    }
+    const int p_m = l0 + 254 + (lane & 3);
+    int i0, i1;
+    wunet_up_coord((lane < 32 && p_m < A.Lt) ? p_m : 0, Lth, A.up_scale, i0, i1, K.mw0, K.mw1);
+}
+// ... and the two source samples of that value (the loads need them three stages before the weights are used)
+__device__ __forceinline__ void wunet_h3u_mini_src(const ConvH3uArgs& A, int l0, int lane, int& i0, int& i1)
+{
+    const int p_m = l0 + 254 + (lane & 3);
+    float w0, w1;
+    wunet_up_coord((lane < 32 && p_m < A.Lt) ? p_m : 0, A.Lt >> 1, A.up_scale, i0, i1, w0, w1);
 }
 
 // The prefetch loads are issued from inline asm: hipcc then neither counts them (its own wait-count bookkeeping put the first use of a tile
 // loaded two stages ago behind a wait for the loads issued a moment before - and a wait in front of every re-use of a register it believed
-// in flight) nor may it touch their destination registers before the loader's own wait (wunet_h3u_wait_tile): the values are asm outputs
-// the compiler believes defined, so nothing but the hand-placed s_waitcnt orders their use.  (Checked in the ISA of each build: no
-// compiler-inserted move reads these registers between the load and the wait.)
-__device__ __forceinline__ wunet_f4 wunet_ld4u_async(const float* p)
+// in flight) nor may it touch their destination registers before the loader's own wait (wunet_vm_wait): the values are asm outputs
+// the compiler believes defined, so nothing but the hand-placed s_waitcnt orders their use.  (Checked in the ISA of each build by
+// tools/check_h3u_isa.py: no instruction touches these registers between the load and the wait.)
+// Scalar-base form: address = sbase (wave-uniform SGPR pair: the channel's row) + voff (the lane's byte offset inside the row, the same
+// register for the 8 channels of a group) - the per-channel part of the address is a scalar add, no 64-bit vector arithmetic per load.
+__device__ __forceinline__ unsigned long long wunet_sgpr64(unsigned long long b)
 {
 #ifdef WUNET_EMU
-    return wunet_ld4(p);
+    return b;
+#else
+    const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return ((unsigned long long)bhi << 32) | blo;                  // (folded away where the compiler already knows the value uniform)
+#endif
+}
+__device__ __forceinline__ wunet_f4 wunet_ld4s_async(unsigned long long sbase, unsigned voff)
+{
+#ifdef WUNET_EMU
+    wunet_f4 v;
+    std::memcpy(&v, reinterpret_cast<const char*>(sbase) + voff, 16);
+    return v;
 #else
     wunet_f4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
     return v;
 #endif
 }
-__device__ __forceinline__ float wunet_ld1_async(const float* p)
+__device__ __forceinline__ float wunet_ld1s_async(unsigned long long sbase, unsigned voff)
 {
 #ifdef WUNET_EMU
-    return *p;
+    float v;
+    std::memcpy(&v, reinterpret_cast<const char*>(sbase) + voff, 4);
+    return v;
 #else
     float v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
     return v;
 #endif
 }
@@ -120,12 +159,46 @@ __device__ __forceinline__ void wunet_vm_wait()
     wunet_sched_fence();            // (register-only arithmetic on the loaded values must not be scheduled above the wait: the compiler sees no dependency)
 #endif
 }
+// One LDS-DMA piece of a group that shares ONE save / restore of M0 (wunet_m0_save / wunet_m0_restore around the group): M0 = lds_base + IMM
+// is written by the add itself.  3 instructions per piece instead of 6 + the address arithmetic of wunet_dma16s.
+__device__ __forceinline__ unsigned wunet_m0_save()
+{
+#ifdef WUNET_EMU
+    return 0;
+#else
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep) :: "memory");
+    return keep;
+#endif
+}
+__device__ __forceinline__ void wunet_m0_restore(unsigned keep)
+{
+#ifndef WUNET_EMU
+    asm volatile("s_mov_b32 m0, %0" :: "s"(keep) : "memory");
+#else
+    (void)keep;
+#endif
+}
+#ifdef WUNET_EMU
+#define wunet_lds_uniform(X_) (X_)
+#else
+#define wunet_lds_uniform(X_) ((unsigned)__builtin_amdgcn_readfirstlane((int)(X_)))
+#endif
+template <int IMM>
+__device__ __forceinline__ void wunet_dma16m(unsigned long long sbase, unsigned voff, wunet_lds_t lds_base)
+{
+#ifdef WUNET_EMU
+    wunet_dma16(reinterpret_cast<const char*>(sbase) + voff, lds_base + IMM);
+#else
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sbase), "s"(lds_base), "n"(IMM) : "memory", "scc");
+#endif
+}
 
 // ONE straight sequence of 10 loads whatever the group is (addresses selected, not branches: a value that is "loaded on one path and kept on
 // another" becomes a copy of the loaded registers, and a copy waits for the load - the prefetch would be serialised): a group beyond C8
-// re-reads the first skip group (its values are dropped), the skip branch's second single load repeats the first.  Returns the number of
-// load instructions issued (10).
-__device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw& R, const WunetH3uTile& T, int cw, int lane)
+// re-reads the first skip group (its BatchNorm coefficients in the block's table are 0: the values become 0), the skip branch's second single
+// load repeats the first.  (mi0, mi1): wunet_h3u_mini_src of the tile's item.  Returns the number of load instructions issued (10).
+__device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw& R, const WunetH3uTile& T, int cw, int lane, int mi0, int mi1)
 {
     if (WUNET_H3U_ABL & 1) return 0;
     const int c8 = wunet_uniform(T.ch * 4 + cw);
@@ -137,27 +210,35 @@ __device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw
     int wb = (T.l0 >> 1) - 2 + 2 * lane;
     wb = wb < 0 ? 0 : (wb > Lth - 4 ? Lth - 4 : wb);
     const int pc = P < 0 ? 0 : (P > L - 4 ? L - 4 : P);
-    int i0, i1;
-    float w0, w1;
-    wunet_up_coord(in_m ? p_m : 0, Lth, A.up_scale, i0, i1, w0, w1);
-    const size_t rs = up ? (size_t)Lh : (size_t)L;                       // row stride of the source
+    const unsigned rs = up ? (unsigned)Lh : (unsigned)L;                 // row stride of the source
     const float* const zrow = up ? A.z0 + ((size_t)T.b * A.C0 + c8 * 8) * Lh : A.z1 + ((size_t)T.b * A.C1 + (none ? 0 : c8 * 8 - A.C0)) * L;
-    const float* const zq = zrow + (up ? wb : pc);
-    const int m0 = up ? i0 : (in_m ? p_m : 0), m1 = up ? i1 : m0;
+    unsigned long long rb = wunet_sgpr64((unsigned long long)(__UINTPTR_TYPE__)zrow);
+    const unsigned long long rb0 = rb;
+    const unsigned voff = (unsigned)(up ? wb : pc) * 4u;
+    const int m0 = up ? mi0 : (in_m ? p_m : 0), m1 = up ? mi1 : m0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) R.q[e] = wunet_ld4u_async(zq + (size_t)e * rs);
-    R.ma = wunet_ld1_async(zrow + (size_t)e_m * rs + m0);
-    R.mb = wunet_ld1_async(zrow + (size_t)e_m * rs + m1);
+    for (int e = 0; e < 8; ++e) {
+        R.q[e] = wunet_ld4s_async(rb, voff);
+        rb = wunet_sgpr64(rb + (unsigned long long)rs * 4u);
+    }
+    R.ma = wunet_ld1s_async(rb0, ((unsigned)e_m * rs + (unsigned)m0) * 4u);
+    R.mb = wunet_ld1s_async(rb0, ((unsigned)e_m * rs + (unsigned)m1) * 4u);
     return 10;
 }
 
-__device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
-                                                  int lane, float xscale, const float* coef, unsigned long long* tr = nullptr)
+// EDGE: the tile starts a row (l0 = 0) - lane 0's window was clamped (its loads started at sample 0, not -2) and its first two samples are
+// the conv's zero padding.  One tile in L / 256; every other tile runs the instantiation without a single select.
+// The BatchNorm coefficients in `coef` are PRE-MULTIPLIED by the operand's power-of-two scale (LeakyReLU and the interpolation commute with
+// it exactly), and are 0 for the channels beyond the operand's last one (their values come out as +0).
+template <bool EDGE>
+__device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
+                                                    int lane, const WunetH3uCoord& K, const float* coef, unsigned long long* tr)
 {
 #ifdef WUNET_H3U_TRACE
 #define WUNET_H3U_SUB(K_) if (tr && cw == 0 && lane == 0) tr[K_] = wunet_memtime();
 #else
 #define WUNET_H3U_SUB(K_)
+    (void)tr;
 #endif
     WUNET_H3U_SUB(0)
     constexpr int COLS = 272, Q4 = COLS / 4;
@@ -170,34 +251,23 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
         return;
     }
     const int c8 = wunet_uniform(T.ch * 4 + cw);
-    const int L = A.L, Lth = A.Lt >> 1;
+    const int L = A.L;
     const bool none = (c8 >= A.C8) || (WUNET_H3U_ABL & 2), up = !none && c8 * 8 < A.C0;
     const bool write_out = A.oxh != nullptr && T.mt0 == 0 && !none;
     // BatchNorm scale / shift of the group's channels from the block's LDS table (a loaded from global memory here would be one more
     // memory round trip per stage - and its wait would drain the prefetched tiles with it)
+    const int cc = (c8 >= A.C8 ? A.C8 : c8) * 8;    // (the table has one more group, all zero)
     float av[8], sv[8];
-    {
-        const int cc = none ? 0 : c8 * 8;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { av[e] = coef[cc + e]; sv[e] = coef[A.C8 * 8 + cc + e]; }
-    }
+    for (int e = 0; e < 8; ++e) { av[e] = coef[cc + e]; sv[e] = coef[(A.C8 + 1) * 8 + cc + e]; }
     WUNET_H3U_SUB(1)
-    // Rows are whole (Lt == L: the planner keeps padded lengths off this kernel), so the only lane whose window was clamped is the one
-    // at the start of a row (P = -2: its loads started two elements later): `edge`.  No branch, no second code path: a few selects.
     const int P = T.l0 - 2 + 4 * lane;
-    const bool edge = P < 0;
+    const bool edge = EDGE && P < 0;
     float vals[4][8];                               // [sample P + j][channel]
     if (up) {
         // ATen's coordinates of the outputs P .. P+3 (wunet_up_coord: fp32, as the reference computes them).  Their source pairs are
         // (wb, wb+1), (wb+1, wb+2), (wb+1, wb+2), (wb+2, wb+3) with wb = (P-2)/2 - i0(j) = (j-1) >> 1 for every j >= 1 at these lengths;
         // output 0 of a row has i0 = 0 with weight 1 on it, which the clamped source index -1 -> 0 reproduces.
-        float w0[4], w1[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int i0, i1;
-            wunet_up_coord(P + j < 0 ? 0 : P + j, Lth, A.up_scale, i0, i1, w0[j], w1[j]);
-            w0[j] *= xscale; w1[j] *= xscale;            // (a power of two: exact, the sum rounds as the unscaled one)
-        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float u[4];
@@ -205,33 +275,30 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
             for (int k = 0; k < 4; ++k) u[k] = wunet_lrelu(av[e] * R.q[e][k] + sv[e]);
             // sources wb .. wb+3 with the row's left clamp: (0, 0, 0, 1) from a window that started at 0
             const float t0 = u[0], t1 = edge ? u[0] : u[1], t2 = edge ? u[0] : u[2], t3 = edge ? u[1] : u[3];
-            vals[0][e] = w0[0] * t0 + w1[0] * t1;
-            vals[1][e] = w0[1] * t1 + w1[1] * t2;
-            vals[2][e] = w0[2] * t1 + w1[2] * t2;
-            vals[3][e] = w0[3] * t2 + w1[3] * t3;
+            vals[0][e] = K.w0[0] * t0 + K.w1[0] * t1;
+            vals[1][e] = K.w0[1] * t1 + K.w1[1] * t2;
+            vals[2][e] = K.w0[2] * t1 + K.w1[2] * t2;
+            vals[3][e] = K.w0[3] * t2 + K.w1[3] * t3;
         }
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float u[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) u[k] = xscale * wunet_lrelu(av[e] * R.q[e][k] + sv[e]);
+            for (int k = 0; k < 4; ++k) u[k] = wunet_lrelu(av[e] * R.q[e][k] + sv[e]);
             vals[0][e] = u[0]; vals[1][e] = u[1];
             vals[2][e] = edge ? u[0] : u[2];             // (a window that started at sample 0: samples 0, 1 are its first two)
             vals[3][e] = edge ? u[1] : u[3];
         }
     }
     WUNET_H3U_SUB(2)
-    bool inside[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) inside[j] = !none && !(edge && j < 2);      // samples -2, -1: the conv's zero padding
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         wunet_h8 h, l;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             wunet_half x, y;
-            wunet_split_h(inside[j] ? vals[j][e] : 0.0f, x, y);
+            wunet_split_h((edge && j < 2) ? 0.0f : vals[j][e], x, y);      // samples -2, -1: the conv's zero padding
             wunet_put_half(h, e, x);
             wunet_put_half(l, e, y);
         }
@@ -253,17 +320,9 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
     if (lane < 32) {
         const int e_m = lane >> 2, p_m = T.l0 + 254 + (lane & 3);
         const bool in_m = !none && p_m < A.Lt;
-        float am = av[0], sm = sv[0];
-#pragma unroll
-        for (int e = 1; e < 8; ++e) { am = e_m == e ? av[e] : am; sm = e_m == e ? sv[e] : sm; }
-        float v;
-        if (up) {
-            int i0, i1;
-            float w0, w1;
-            wunet_up_coord(in_m ? p_m : 0, Lth, A.up_scale, i0, i1, w0, w1);
-            w0 *= xscale; w1 *= xscale;
-            v = w0 * wunet_lrelu(am * R.ma + sm) + w1 * wunet_lrelu(am * R.mb + sm);
-        } else v = xscale * wunet_lrelu(am * R.ma + sm);
+        const float am = coef[cc + e_m], sm = coef[(A.C8 + 1) * 8 + cc + e_m];
+        const float ua = wunet_lrelu(am * R.ma + sm);
+        const float v = up ? K.mw0 * ua + K.mw1 * wunet_lrelu(am * R.mb + sm) : ua;
         wunet_half x, y;
         wunet_split_h(in_m ? v : 0.0f, x, y);
         const int col = 262 + (lane & 3);
@@ -276,6 +335,13 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
             A.oxl[o] = y;
         }
     }
+#undef WUNET_H3U_SUB
+}
+__device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
+                                                  int lane, const WunetH3uCoord& K, const float* coef, unsigned long long* tr = nullptr)
+{
+    if (wunet_uniform(T.l0) == 0) wunet_h3u_convert_t<true>(A, R, T, xs, cw, lane, K, coef, tr);
+    else wunet_h3u_convert_t<false>(A, R, T, xs, cw, lane, K, coef, tr);
 }
 
 // (-DWUNET_H3U_TRACE, tools/h3u_trace.py: lane 0 of MFMA wave 0 / loader wave 0 stamps its arrival at and its release from every stage
@@ -303,7 +369,9 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
     wunet_half* const xs0 = reinterpret_cast<wunet_half*>(smem);          // [2][hi|lo][4][COLS, de-interleaved][8]
     wunet_half* const ws0 = xs0 + 2 * XP * 8;                              // [2][hi|lo][M_REP][TG][4][16][8]
     float* const red = reinterpret_cast<float*>(ws0 + 2 * WP * 8);        // [4 waves][M_REP * 16][2] statistics hand-over
-    float* const coef = red + WUNET_WAVES * M_REP * 32 + 4;                // [a | s][C8 * 8]: BatchNorm scale / shift of the operand's channels
+    float* const coef = red + WUNET_WAVES * M_REP * 32 + 4;                // [a | s][(C8 + 1) * 8]: BatchNorm scale / shift of the operand's channels
+    const int ER = A.mblocks * M_REP * 16;
+    float* const epi = coef + 2 * (A.C8 + 1) * 8;                          // [bias | eval a | eval s][ER]: the epilogue's per-row constants
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wunet_uniform(tid >> 6);
     const int cw = wave & 3;                      // MFMA wave / loader wave index
@@ -317,10 +385,19 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
     wunet_h3u_x_scale(A.xb0, A.xb1, xs_, xinv_);
     if (blockIdx.x == 0 && tid == 0 && A.xsc) { A.xsc[0] = xs_; A.xsc[1] = xinv_; }
 
-    for (int c = tid; c < A.C8 * 8; c += 2 * WUNET_THREADS) {
+    // [a | s] x (C8 + 1) groups, times the operand's scale; channels beyond the operand's and the extra group: 0
+    for (int c = tid; c < (A.C8 + 1) * 8; c += 2 * WUNET_THREADS) {
         const bool u = c < A.C0, k = c < A.C0 + A.C1;
-        coef[c] = u ? A.a0[c] : k ? A.a1[c - A.C0] : 0.0f;
-        coef[A.C8 * 8 + c] = u ? A.s0[c] : k ? A.s1[c - A.C0] : 0.0f;
+        coef[c] = xs_ * (u ? A.a0[c] : k ? A.a1[c - A.C0] : 0.0f);
+        coef[(A.C8 + 1) * 8 + c] = xs_ * (u ? A.s0[c] : k ? A.s1[c - A.C0] : 0.0f);
+    }
+    // (from global memory they were one memory round trip per work item with the matrix pipe idle: this kernel has no second block on the
+    //  CU to fill it)
+    for (int c = tid; c < ER; c += 2 * WUNET_THREADS) {
+        const bool in = c < A.Cout;
+        epi[c] = (in && A.bias) ? A.bias[c] : 0.0f;
+        epi[ER + c] = (in && A.xrows) ? A.ev_a[c] : 0.0f;
+        epi[2 * ER + c] = (in && A.xrows) ? A.ev_s[c] : 0.0f;
     }
     __syncthreads();
     // Both roles run the SAME sequence of workgroup barriers: one per stage (the stage's buffers are complete - the loaders waited for
@@ -331,23 +408,38 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         const wunet_lds_t ws_a = wunet_lds_addr(ws0);
         const unsigned wo_all = (unsigned)(cw * 64 + lane) * 16u, wo_rest = (256u + (unsigned)lane) * 16u;
         const int T = nmy * A.NS;                 // stages of this block, tile t = (item t / NS, chunk t % NS)
-#define WUNET_H3U_TILE(T_, OUT_)                                                                                   \
+        const WunetH3uStep S{A.NS, A.mblocks, G / A.mblocks, G % A.mblocks};
+#define WUNET_H3U_TILE(CUR_, OUT_)                                                                                 \
     WunetH3uTile OUT_;                                                                                             \
-    {                                                                                                              \
-        const int k_ = (T_) / A.NS, v_ = (int)blockIdx.x + k_ * G, tile_ = v_ / A.mblocks;                         \
-        OUT_.ch = (T_) - k_ * A.NS; OUT_.mt0 = (v_ - tile_ * A.mblocks) * M_REP;                                   \
-        OUT_.b = (tile_ * 256) >> A.logL; OUT_.l0 = (tile_ * 256) & (L - 1);                                       \
-    }
-        // W sub-tile of a stage: per (plane, m-tile) a contiguous run of 320 pieces in the pack and in LDS
+    OUT_.ch = (CUR_).ch; OUT_.mt0 = (CUR_).mb * M_REP;                                                             \
+    OUT_.b = ((CUR_).tile * 256) >> A.logL; OUT_.l0 = ((CUR_).tile * 256) & (L - 1);
+        // W sub-tile of a stage: per (plane, m-tile) a contiguous run of 320 pieces in the pack and in LDS; wave cw moves pieces
+        // cw * 64 .. + 63 of every run and the last 64 of the runs with sub % 4 == cw
+        const unsigned long long wrun = (unsigned long long)A.NS * (TG * 64 * 16);
 #define WUNET_H3U_DMA_W(TL_, P_)                                                                                   \
-    {                                                                                                              \
-        const char* const wbase_ = reinterpret_cast<const char*>(A.wh) + (long long)((((size_t)(TL_).mt0 * A.NS + (TL_).ch) * TG * 64) * 16); \
+    if (!(WUNET_H3U_ABL & 8)) {                                                                                    \
+        const unsigned long long wb_ = (unsigned long long)(__UINTPTR_TYPE__)A.wh                                  \
+                                     + (unsigned long long)((size_t)(TL_).mt0 * A.NS + (TL_).ch) * (TG * 64 * 16); \
+        const wunet_lds_t la_ = ws_a + ((P_) * WP + cw * 64) * 16, lr_ = ws_a + ((P_) * WP + 256) * 16;            \
+        const unsigned keep_ = wunet_m0_save();                                                                    \
         _Pragma("unroll") for (int sub = 0; sub < 2 * M_REP; ++sub) {                                              \
-            const char* const run_ = wbase_ + (long long)(sub % M_REP) * A.NS * (TG * 64 * 16) + (sub >= M_REP ? (long long)A.wdelta : 0LL); \
-            if (!(WUNET_H3U_ABL & 8)) wunet_dma16s(run_, wo_all, ws_a + ((P_) * WP + sub * WPM + cw * 64) * 16);  \
-            if (!(WUNET_H3U_ABL & 8) && cw == (sub & 3)) wunet_dma16s(run_, wo_rest, ws_a + ((P_) * WP + sub * WPM + 256) * 16); \
+            const unsigned long long run_ = wunet_sgpr64(wb_ + (unsigned long long)(sub % M_REP) * wrun + (sub >= M_REP ? (unsigned long long)A.wdelta : 0ull)); \
+            WUNET_H3U_DMA_PIECE(sub, run_, wo_all, la_)                                                            \
+            if (cw == (sub & 3)) { WUNET_H3U_DMA_PIECE(sub, run_, wo_rest, lr_) }                                  \
         }                                                                                                          \
+        wunet_m0_restore(keep_);                                                                                   \
     }
+        // (the LDS offset of run `sub` is an immediate of the instruction that writes M0: a switch over the unrolled loop's constant)
+#define WUNET_H3U_DMA_PIECE(SUB_, RUN_, VOFF_, LB_)                                                                \
+    switch (SUB_) {                                                                                                \
+    case 0: wunet_dma16m<0 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    case 1: wunet_dma16m<1 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    case 2: wunet_dma16m<2 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    case 3: wunet_dma16m<3 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    case 4: wunet_dma16m<4 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    default: wunet_dma16m<5 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                               \
+    }
+        static_assert(M_REP <= 3, "six runs per W sub-tile");
         // Tile t's loads are issued three stages before the MFMA waves need it: in stage t the loaders convert tile t + 1 (loaded two
         // stages ago) into the other buffer while the loads of tiles t + 2 and t + 3 are in flight - memory latency under load (2 - 3 us)
         // is several stage times.  R0 / R1 / R2 rotate by unrolling, not by moves.
@@ -356,16 +448,29 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         // the older loads are the youngest ones outstanding, and the first use of a tile loaded two stages ago then waits for the loads
         // issued a moment before it - the prefetch collapses to one memory latency per stage.)
         WunetH3uRaw R0, R1, R2;
+        WunetH3uCursor c1, c3;                    // the tiles t + 1 (converted in stage t) and min(t + 3, T - 1) (loaded in stage t)
+        int i3;                                   // c3's stage number
+        WunetH3uCoord K;                          // of c1's item
+        int mi0, mi1;                             // of c3's item
         {
-            WUNET_H3U_TILE(0, t0)
-            WUNET_H3U_TILE(T > 1 ? 1 : 0, t1)
-            WUNET_H3U_TILE(T > 2 ? 2 : T - 1, t2)
-            wunet_h3u_issue(A, R0, t0, cw, lane);
-            wunet_h3u_issue(A, R1, t1, cw, lane);
+            const int tile0 = (int)blockIdx.x / A.mblocks;
+            c1 = WunetH3uCursor{0, tile0, (int)blockIdx.x - tile0 * A.mblocks};
+            WUNET_H3U_TILE(c1, t0)
+            c3 = c1; i3 = 0;
+            if (T > 1) { wunet_h3u_advance(c3, S); ++i3; }
+            WUNET_H3U_TILE(c3, t1)
+            wunet_h3u_coord(A, t0.l0, lane, K);
+            wunet_h3u_mini_src(A, t0.l0, lane, mi0, mi1);
+            wunet_h3u_issue(A, R0, t0, cw, lane, mi0, mi1);
+            if (t1.ch == 0) wunet_h3u_mini_src(A, t1.l0, lane, mi0, mi1);
+            wunet_h3u_issue(A, R1, t1, cw, lane, mi0, mi1);
             WUNET_H3U_DMA_W(t0, 0)
-            wunet_h3u_issue(A, R2, t2, cw, lane);
+            if (T > 2) { wunet_h3u_advance(c3, S); ++i3; }
+            WUNET_H3U_TILE(c3, t2)
+            if (t2.ch == 0) wunet_h3u_mini_src(A, t2.l0, lane, mi0, mi1);
+            wunet_h3u_issue(A, R2, t2, cw, lane, mi0, mi1);
             wunet_vm_wait<0>();
-            wunet_h3u_convert(A, R0, t0, xs0, cw, lane, xs_, coef);
+            wunet_h3u_convert(A, R0, t0, xs0, cw, lane, K, coef);
         }
         // stage t (< T - 1): CUR_ holds the loads of tile t + 1, FREE_ (tile t's, converted a stage ago) takes those of tile t + 3; 10 loads
         // (tile t + 3's) are younger than the stage's last DMA piece at the next barrier
@@ -374,15 +479,19 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         WUNET_H3U_STAMP(1, t, 0)                                                                                   \
         wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                                                        \
         WUNET_H3U_STAMP(1, t, 1)                                                                                   \
-        WUNET_H3U_TILE(t + 1, tn)                                                                                  \
+        wunet_h3u_advance(c1, S);                                                                                  \
+        WUNET_H3U_TILE(c1, tn)                                                                                     \
         WUNET_H3U_DMA_W(tn, (t + 1) & 1)                                                                           \
-        WUNET_H3U_TILE(t + 3 < T ? t + 3 : T - 1, tnn)                                                             \
-        wunet_h3u_issue(A, FREE_, tnn, cw, lane);                                                                  \
+        if (i3 < T - 1) { wunet_h3u_advance(c3, S); ++i3; }                                                        \
+        WUNET_H3U_TILE(c3, tnn)                                                                                    \
+        if (tnn.ch == 0) wunet_h3u_mini_src(A, tnn.l0, lane, mi0, mi1);                                            \
+        wunet_h3u_issue(A, FREE_, tnn, cw, lane, mi0, mi1);                                                        \
+        if (tn.ch == 0) wunet_h3u_coord(A, tn.l0, lane, K);                                                        \
         /* tile t + 1's loads have landed: younger than them are the loads of tiles t + 2 and t + 3 (20) and the DMA pieces of two  \
            stages (>= 2 M_REP + 1 per wave and stage); with the operand's copy to HBM in the queue as well (training) everything */  \
         if (A.oxh) wunet_vm_wait<0>(); else wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                              \
-        wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, xs_, coef, WUNET_H3U_SUBPTR);       \
-        if (want_stats && (t + 1) % A.NS == 0) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                 \
+        wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, K, coef, WUNET_H3U_SUBPTR);          \
+        if (want_stats && tn.ch == 0) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                 \
         ++t;                                                                                                       \
     }
         int t = 0;
@@ -398,6 +507,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         if (want_stats) wunet_loader_barrier(0);
 #undef WUNET_H3U_LOADER_STAGE
 #undef WUNET_H3U_DMA_W
+#undef WUNET_H3U_DMA_PIECE
 #undef WUNET_H3U_TILE
         return;
     }
@@ -409,6 +519,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
     const int aoff = (q * 16 + i16) * 8;
     int par = 0;                                  // buffer the coming stage reads
     float amax_run = 0.0f;
+    const float inv12 = xinv_ * (A.sc2 ? A.sc2[1] : 1.0f);       // un-scale of operand and weights (two powers of two: the product is exact)
     for (int k = 0; k < nmy; ++k) {
         const int v = (int)blockIdx.x + k * G, tile = v / A.mblocks, mblk = v - tile * A.mblocks;
         const int b = (tile * 256) >> A.logL, l0 = (tile * 256) & (L - 1), mt0 = mblk * M_REP;
@@ -467,16 +578,12 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         // ---- epilogue (conv_h3d_kernel's): un-scale, bias, store, BatchNorm statistics of the bias-free conv / eval activation bound.
         // The loaders are filling the next item's first buffers meanwhile.
         {
-            const float inv = xinv_, inv2 = A.sc2 ? A.sc2[1] : 1.0f;
             float amax = 0.0f;
             float bvs[M_REP][4];
 #pragma unroll
             for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = (mt0 + mt) * 16 + q * 4 + r;
-                    bvs[mt][r] = (A.bias && co < A.Cout) ? A.bias[co] : 0.0f;
-                }
+                for (int r = 0; r < 4; ++r) bvs[mt][r] = epi[(mt0 + mt) * 16 + q * 4 + r];
             float* const prow = A.out + ((size_t)b * A.Cout + mt0 * 16 + q * 4) * L + (l0 + ll0);
             const bool full = (mt0 + M_REP) * 16 <= A.Cout;
 #define WUNET_H3U_ROWS(STATS_, GUARD_, EVAL_)                                                                     \
@@ -485,8 +592,8 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
                 const int co = (mt0 + mt) * 16 + q * 4 + r;                                                       \
-                eas[mt][r] = co < A.Cout ? A.ev_a[co] : 0.0f;                                                     \
-                ess[mt][r] = co < A.Cout ? A.ev_s[co] : 0.0f;                                                     \
+                eas[mt][r] = epi[ER + co];                                                                        \
+                ess[mt][r] = epi[2 * ER + co];                                                                    \
             }                                                                                                     \
     }                                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
@@ -496,7 +603,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
             const float bv = bvs[mt][r];                                                                          \
             wunet_f4 o;                                                                                           \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
-                const float vv = acc[mt][nt][r] * inv * inv2;                                                     \
+                const float vv = acc[mt][nt][r] * inv12;                                                          \
                 if (STATS_) { s1[r] += vv; s2[r] = fmaf(vv, vv, s2[r]); }                                         \
                 o[nt] = vv + bv;                                                                                  \
             }                                                                                                     \
