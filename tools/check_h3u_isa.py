@@ -1,8 +1,10 @@
 """conv_h3u_kernel's loader waves issue their prefetch loads from inline asm and order their use with hand-placed s_waitcnt (wunet_h3u.h):
 hipcc neither counts those loads nor protects their destination registers.  This checks, in the ISA hipcc generated for THIS build, the one
-thing the scheme depends on: between a prefetch load and the wait that covers it (the third `s_waitcnt vmcnt(20 + ...)` after it - the
-loads of a tile are consumed two stages later) NO instruction reads or writes the load's destination registers - no compiler-inserted
-copy, no re-use as a temporary.  The steady loop is walked cyclically (three unrolled stages, rotating register sets).
+thing the scheme depends on: between a prefetch load and the wait that covers it (the SECOND stage barrier `s_waitcnt vmcnt(10) lgkmcnt(0)`
+after it - a stage's barrier lets only the 10 loads issued in that stage stay outstanding, so the loads of the stage before have landed; they
+are consumed in the stage that follows) NO instruction reads or writes the load's destination registers - no compiler-inserted copy, no re-use
+as a temporary.  The steady loop is walked cyclically (three unrolled stages, rotating register sets).  (The per-item barrier of the
+statistics hand-over is written `s_waitcnt lgkmcnt(0) vmcnt(10)` and not counted; the vmcnt(0) forms are the stricter alternative paths.)
 
     python tools/check_h3u_isa.py            # compiles csrc/h3u_inst.cpp to ISA with hipcc and checks every instantiation
 Exit code 0 = clean.  Run by tests/test_abi.py (CPU: hipcc cross-compiles) so a compiler or source change that breaks the assumption fails the suite.
@@ -42,36 +44,6 @@ def kernels(asm):
                 cur = None
 
 
-def _sgpr_dead(ins, labels, j, sreg, depth=0):
-    """True if scalar register `sreg`, written by instruction j, is overwritten before it is read on every path (followed through
-    up to three conditional branches): the write is dead - hipcc leaves such a v_readfirstlane of an UNDEFINED operand behind (any VGPR
-    serves as "undefined", also one with a load in flight); its result reaches nothing."""
-    pat = re.compile(r"\b%s\b" % re.escape(sreg))
-    k = j + 1
-    while k < len(ins) and k < j + 400:
-        t = ins[k][0]
-        k += 1
-        if t is None:
-            continue
-        m = re.match(r"(asm )?(s_c?branch\w*)\s+(\.LBB\d+_\d+)", t)
-        if m:
-            tgt = labels.get(m.group(3))
-            if m.group(2) == "s_branch":
-                if tgt is None:
-                    return False
-                k = tgt
-                continue
-            if depth >= 3 or tgt is None or not _sgpr_dead(ins, labels, tgt, sreg, depth + 1):
-                return False
-            continue
-        if not pat.search(t):
-            continue
-        ops = t.split(None, 1)[1] if " " in t else ""
-        first, rest = (ops.split(",", 1) + [""])[:2]
-        return bool(pat.search(first)) and not pat.search(rest) and t.startswith(("s_", "v_readfirstlane", "v_readlane"))
-    return False
-
-
 def check(name, lines):
     ins = []                                   # (text, label or None); instructions of inline-asm blocks carry the prefix "asm "
     in_asm = False
@@ -81,63 +53,165 @@ def check(name, lines):
         elif "#ASMEND" in ln:
             in_asm = False
         t = ln.split(";")[0].strip()
-        if t and in_asm:
-            t = "asm " + t
-        if not t or t.startswith("."):
-            if re.match(r"^\.LBB\d+_\d+:", t):
-                ins.append((None, t[:-1]))
+        if not t or t.startswith("#"):
             continue
-        ins.append((t, None))
+        m = re.match(r"^(\.\w+):$", t)
+        if m:
+            ins.append((None, m.group(1)))
+            continue
+        if t.startswith("."):
+            continue
+        ins.append((("asm " + t) if in_asm else t, None))
     labels = {lab: i for i, (t, lab) in enumerate(ins) if lab}
     is_load = lambda t: t is not None and re.match(r"asm global_load_dword(x4)? v", t)
-    is_tile_wait = lambda t: t is not None and re.match(r"asm s_waitcnt vmcnt\((2\d|3\d|4\d)\)$", t)
+    is_stage_barrier = lambda t: t is not None and re.match(r"asm s_waitcnt vmcnt\(10\) lgkmcnt\(0\)$", t)
+    is_full_wait = lambda t: t is not None and re.search(r"s_waitcnt (lgkmcnt\(0\) )?vmcnt\(0\)", t)
     loads = [i for i, (t, _) in enumerate(ins) if is_load(t)]
-    waits = [i for i, (t, _) in enumerate(ins) if is_tile_wait(t)]
-    if not loads or len(waits) < 3:
-        return [f"{name}: expected asm prefetch loads and >= 3 tile waits, found {len(loads)} / {len(waits)}"]
-    # the steady loop: the backward branch behind the last tile wait, to its target label
-    back = None
-    for i in range(len(ins) - 1, waits[-1], -1):
+    nbar = sum(1 for t, _ in ins if is_stage_barrier(t))
+    if not loads or nbar < 3:
+        return [f"{name}: expected asm prefetch loads and >= 3 stage barriers, found {len(loads)} / {nbar}"]
+
+    def succ(i):
         t = ins[i][0]
-        m = t and re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", t)
-        if m and labels.get(m.group(1), 1 << 30) < waits[0 if len(waits) == 3 else -3]:
-            back = (labels[m.group(1)], i)
-            break
-    if back is None:
-        return [f"{name}: loop of the loader waves not found"]
-    head, tail = back
-    body = list(range(head, tail + 1))
-    order = list(range(loads[0], head)) + body + body + body          # prologue, then the loop three times round
-    errs = []
-    seen = set()
-    for pos, i in enumerate(order):
+        if t is None:
+            return [i + 1]
+        u = t[4:] if t.startswith("asm ") else t
+        if u.startswith("s_endpgm"):
+            return []
+        m = re.match(r"(s_c?branch\w*)\s+(\.\w+)", u)
+        if m:
+            tgt = labels.get(m.group(2))
+            if tgt is None:
+                return [i + 1]
+            return [tgt] if m.group(1) == "s_branch" else [i + 1, tgt]
+        return [i + 1]
+
+    # hipcc structurizes the loop exits through flag registers (`s_mov_b64 s[6:7], -1 ... s_and_b64 vcc, exec, s[6:7]; s_cbranch_vccnz <exit>`
+    # in a block several paths share): followed blindly such a block links the end of one unrolled stage to the head of the same one.  The walk
+    # therefore carries the flag pairs it has seen set to 0 / -1 and vcc derived from them, and takes only the feasible side of such a branch.
+    PAIR = re.compile(r"s\[(\d+):(\d+)\]")
+
+    def step_state(u, st):
+        """st: tuple of sorted (key, value) - keys 'vcc' or (lo, hi); returns the state behind instruction u."""
+        d = dict(st)
+        v = u[4:] if u.startswith("asm ") else u
+        m = re.match(r"s_mov_b64 s\[(\d+):(\d+)\], (-1|0)$", v)
+        if m:
+            d[(int(m.group(1)), int(m.group(2)))] = int(m.group(3))
+            return tuple(sorted(d.items(), key=str))
+        m = re.match(r"s_(and|andn2)_b64 vcc, exec, s\[(\d+):(\d+)\]$", v)
+        if m:
+            k = (int(m.group(2)), int(m.group(3)))
+            if k in d:
+                d["vcc"] = (d[k] != 0) if m.group(1) == "and" else (d[k] == 0)
+            else:
+                d.pop("vcc", None)
+            return tuple(sorted(d.items(), key=str))
+        if re.match(r"s_cbranch_", v):
+            return st
+        # exec: known non-zero (a running wave outside a lane-masked region) or unknown
+        if re.match(r"s_\w+_saveexec_b64", v) or re.match(r"(s_and_b64|s_andn2_b64|s_xor_b64|s_mov_b64) exec,", v) or v.startswith("v_cmpx"):
+            d.pop("exec", None)
+        elif re.match(r"s_or_b64 exec, exec, ", v):
+            d["exec"] = True                               # (the mask saved before the region is put back)
+        if "vcc" in v or re.match(r"v_cmpx?_\w+_e32", v) or v.startswith("v_div_scale") or v.startswith("asm"):
+            d.pop("vcc", None)
+        sregs = set()
+        for m in PAIR.finditer(v):
+            sregs.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        for m in re.finditer(r"\bs(\d+)\b", v):
+            sregs.add(int(m.group(1)))
+        for k in [k for k in d if not isinstance(k, str) and (k[0] in sregs or k[1] in sregs)]:
+            del d[k]
+        return tuple(sorted(d.items(), key=str))
+
+    def succ_state(i, st):
         t = ins[i][0]
-        if not is_load(t) or (i in seen and i >= head):
-            continue
-        seen.add(i)
-        dest = regs_of(t[4:].split(",")[0])
-        nw = 0
-        for j in order[pos + 1:]:
-            u = ins[j][0]
+        if t is not None:
+            u = t[4:] if t.startswith("asm ") else t
+            m = re.match(r"s_cbranch_(vcc|exec)(nz|z)\s+(\.\w+)", u)
+            d = dict(st)
+            if m and m.group(1) in d and m.group(3) in labels:
+                taken = d[m.group(1)] if m.group(2) == "nz" else not d[m.group(1)]
+                return [labels[m.group(3)]] if taken else [i + 1]
+        return succ(i)
+
+    def value_dead(j, sreg, st0):
+        """hipcc leaves `v_readfirstlane_b32 sN, vK` of an UNDEFINED operand behind on loop-exit paths (any VGPR serves as "undefined", also one
+        with a load in flight).  True if on every feasible path behind instruction j the scalar it wrote - and every plain copy of it - is
+        overwritten or the program ends before anything else reads it."""
+        seen_, todo = set(), [(k, frozenset([sreg]), step_state(ins[j][0], st0)) for k in succ_state(j, st0)]
+        steps = 0
+        while todo:
+            i, taint, st = todo.pop()
+            if i >= len(ins) or not taint or (i, taint, st) in seen_:
+                continue
+            seen_.add((i, taint, st))
+            steps += 1
+            if steps > 200000:
+                return False
+            u = ins[i][0]
             if u is None:
+                todo.append((i + 1, taint, st))
                 continue
-            if is_tile_wait(u):
-                nw += 1
-                if nw == 3:
-                    break
+            v = u[4:] if u.startswith("asm ") else u
+            ops = v.split(None, 1)[1] if " " in v else ""
+            first, rest = (ops.split(",", 1) + [""])[:2]
+
+            def sset(text):
+                r = set()
+                for m in PAIR.finditer(text):
+                    r.update(range(int(m.group(1)), int(m.group(2)) + 1))
+                for m in re.finditer(r"\bs(\d+)\b", text):
+                    r.add(int(m.group(1)))
+                return r
+            writes_first = v.startswith(("s_", "v_readfirstlane", "v_readlane")) and not v.startswith(("s_cmp", "s_bitcmp", "s_cbranch", "s_branch", "s_waitcnt", "s_barrier", "s_nop", "s_endpgm"))
+            reads = sset(rest) if writes_first else sset(ops)
+            if reads & taint:
+                m = re.match(r"s_mov_b32 s(\d+), s(\d+)$", v)
+                if not m:
+                    return False
+                taint = taint | {int(m.group(1))}
+            elif writes_first:
+                taint = taint - sset(first)
+            if v.startswith("s_endpgm"):
                 continue
-            if i < head and nw == 0 and u.startswith("asm s_waitcnt vmcnt(0)"):
-                break                                                   # (prologue: tile 0 is waited for with vmcnt(0))
-            if is_load(u) and regs_of(u[4:].split(",")[0]) & dest:
-                errs.append(f"{name}: `{t}` is overwritten by `{u}` before its wait")
-            elif not is_load(u) and regs_of(u) & dest:
-                m = re.match(r"v_readfirstlane_b32 (s\d+), v\d+$", u)
-                if m and _sgpr_dead(ins, labels, j, m.group(1)):
-                    continue
-                errs.append(f"{name}: `{u}` touches v{sorted(regs_of(u) & dest)} while `{t}` may be in flight")
-        else:
-            if i >= head:
-                errs.append(f"{name}: no third wait behind `{t}`")
+            nst = step_state(u, st)
+            for k in succ_state(i, st):
+                todo.append((k, taint, nst))
+        return True
+
+    errs = []
+    for x in loads:
+        t = ins[x][0]
+        dest = regs_of(t[4:].split(",")[0])
+        seen = set()
+        stack = [(j, 0, (("exec", True),)) for j in succ(x)]     # (the prefetch loads are issued by whole waves)
+        bad = {}
+        while stack:
+            j, nb, st = stack.pop()
+            if j >= len(ins) or (j, nb, st) in seen:
+                continue
+            seen.add((j, nb, st))
+            u = ins[j][0]
+            nxt = succ(j)
+            if u is not None:
+                if is_full_wait(u):
+                    continue                               # everything this wave issued has landed
+                if is_stage_barrier(u):
+                    nb += 1
+                    if nb == 2:
+                        continue
+                elif regs_of(u) & dest and j not in bad:
+                    m = re.match(r"v_readfirstlane_b32 s(\d+), v\d+$", u)
+                    if not (m and value_dead(j, int(m.group(1)), st)):
+                        bad[j] = u
+                nxt = succ_state(j, st)
+                st = step_state(u, st)
+            for k in nxt:
+                stack.append((k, nb, st))
+        for j, u in sorted(bad.items())[:3]:
+            errs.append(f"{name}: `{u}` (instruction {j}) touches v{sorted(regs_of(u) & dest)} while `{t}` (instruction {x}) may be in flight")
     return errs
 
 

@@ -11,6 +11,6 @@
 
 int wunet_launch_conv_h3u(const ConvH3uArgs& a, int mrep, dim3 grid, size_t smem, hipStream_t st)
 {
-    WUNET_UCASE(2) WUNET_UCASE(3)
+    WUNET_UCASE(2) WUNET_UCASE(3) WUNET_UCASE(4)
     return -1;
 }

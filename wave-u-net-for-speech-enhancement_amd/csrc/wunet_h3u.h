@@ -196,8 +196,7 @@ __device__ __forceinline__ void wunet_dma16m(unsigned long long sbase, unsigned 
 
 // ONE straight sequence of 10 loads whatever the group is (addresses selected, not branches: a value that is "loaded on one path and kept on
 // another" becomes a copy of the loaded registers, and a copy waits for the load - the prefetch would be serialised): a group beyond C8
-// re-reads the first skip group (its BatchNorm coefficients in the block's table are 0: the values become 0), the skip branch's second single
-// load repeats the first.  (mi0, mi1): wunet_h3u_mini_src of the tile's item.  Returns the number of load instructions issued (10).
+// reads 16 bytes of the first row ten times (its values are never used), the skip branch's second single load repeats the first.  (mi0, mi1): wunet_h3u_mini_src of the tile's item.  Returns the number of load instructions issued (10).
 __device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw& R, const WunetH3uTile& T, int cw, int lane, int mi0, int mi1)
 {
     if (WUNET_H3U_ABL & 1) return 0;
@@ -210,26 +209,26 @@ __device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw
     int wb = (T.l0 >> 1) - 2 + 2 * lane;
     wb = wb < 0 ? 0 : (wb > Lth - 4 ? Lth - 4 : wb);
     const int pc = P < 0 ? 0 : (P > L - 4 ? L - 4 : P);
-    const unsigned rs = up ? (unsigned)Lh : (unsigned)L;                 // row stride of the source
-    const float* const zrow = up ? A.z0 + ((size_t)T.b * A.C0 + c8 * 8) * Lh : A.z1 + ((size_t)T.b * A.C1 + (none ? 0 : c8 * 8 - A.C0)) * L;
+    const unsigned rs = none ? 0u : up ? (unsigned)Lh : (unsigned)L;     // row stride of the source
+    const float* const zrow = up ? A.z0 + ((size_t)T.b * A.C0 + c8 * 8) * Lh : none ? A.z1 : A.z1 + ((size_t)T.b * A.C1 + (c8 * 8 - A.C0)) * L;
     unsigned long long rb = wunet_sgpr64((unsigned long long)(__UINTPTR_TYPE__)zrow);
     const unsigned long long rb0 = rb;
-    const unsigned voff = (unsigned)(up ? wb : pc) * 4u;
+    const unsigned voff = none ? 0u : (unsigned)(up ? wb : pc) * 4u;
     const int m0 = up ? mi0 : (in_m ? p_m : 0), m1 = up ? mi1 : m0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         R.q[e] = wunet_ld4s_async(rb, voff);
         rb = wunet_sgpr64(rb + (unsigned long long)rs * 4u);
     }
-    R.ma = wunet_ld1s_async(rb0, ((unsigned)e_m * rs + (unsigned)m0) * 4u);
-    R.mb = wunet_ld1s_async(rb0, ((unsigned)e_m * rs + (unsigned)m1) * 4u);
+    R.ma = wunet_ld1s_async(rb0, none ? 0u : ((unsigned)e_m * rs + (unsigned)m0) * 4u);
+    R.mb = wunet_ld1s_async(rb0, none ? 0u : ((unsigned)e_m * rs + (unsigned)m1) * 4u);
     return 10;
 }
 
 // EDGE: the tile starts a row (l0 = 0) - lane 0's window was clamped (its loads started at sample 0, not -2) and its first two samples are
 // the conv's zero padding.  One tile in L / 256; every other tile runs the instantiation without a single select.
 // The BatchNorm coefficients in `coef` are PRE-MULTIPLIED by the operand's power-of-two scale (LeakyReLU and the interpolation commute with
-// it exactly), and are 0 for the channels beyond the operand's last one (their values come out as +0).
+// it exactly).
 template <bool EDGE>
 __device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
                                                     int lane, const WunetH3uCoord& K, const float* coef, unsigned long long* tr)
@@ -252,14 +251,31 @@ __device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const 
     }
     const int c8 = wunet_uniform(T.ch * 4 + cw);
     const int L = A.L;
-    const bool none = (c8 >= A.C8) || (WUNET_H3U_ABL & 2), up = !none && c8 * 8 < A.C0;
-    const bool write_out = A.oxh != nullptr && T.mt0 == 0 && !none;
+    const bool none = c8 >= A.C8, up = !none && c8 * 8 < A.C0;
+    if (none) {                                     // a group beyond the operand's last one (the weight pack's rows of these channels are 0): zeros
+        const wunet_h8 z{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 4 * lane + 6 + j;
+            const int pw = (cw * COLS + (col & 3) * Q4 + (col >> 2)) * 8;
+            wunet_sth8(xs + pw, z);
+            wunet_sth8(xs + 4 * COLS * 8 + pw, z);
+        }
+        if (lane < 32) {
+            const int col = 262 + (lane & 3);
+            const int pw = (cw * COLS + (col & 3) * Q4 + (col >> 2)) * 8 + (lane >> 2);
+            xs[pw] = 0;
+            xs[4 * COLS * 8 + pw] = 0;
+        }
+        return;
+    }
+    const bool write_out = A.oxh != nullptr && T.mt0 == 0;
     // BatchNorm scale / shift of the group's channels from the block's LDS table (a loaded from global memory here would be one more
     // memory round trip per stage - and its wait would drain the prefetched tiles with it)
-    const int cc = (c8 >= A.C8 ? A.C8 : c8) * 8;    // (the table has one more group, all zero)
+    const int cc = c8 * 8;
     float av[8], sv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { av[e] = coef[cc + e]; sv[e] = coef[(A.C8 + 1) * 8 + cc + e]; }
+    for (int e = 0; e < 8; ++e) { av[e] = coef[cc + e]; sv[e] = coef[A.C8 * 8 + cc + e]; }
     WUNET_H3U_SUB(1)
     const int P = T.l0 - 2 + 4 * lane;
     const bool edge = EDGE && P < 0;
@@ -319,8 +335,8 @@ __device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const 
     // columns 262 .. 265 (samples l0 + 254 .. 257): channel lane >> 2, sample lane & 3 of lanes 0 .. 31, two bytes per plane each
     if (lane < 32) {
         const int e_m = lane >> 2, p_m = T.l0 + 254 + (lane & 3);
-        const bool in_m = !none && p_m < A.Lt;
-        const float am = coef[cc + e_m], sm = coef[(A.C8 + 1) * 8 + cc + e_m];
+        const bool in_m = p_m < A.Lt;
+        const float am = coef[cc + e_m], sm = coef[A.C8 * 8 + cc + e_m];
         const float ua = wunet_lrelu(am * R.ma + sm);
         const float v = up ? K.mw0 * ua + K.mw1 * wunet_lrelu(am * R.mb + sm) : ua;
         wunet_half x, y;
@@ -369,9 +385,9 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
     wunet_half* const xs0 = reinterpret_cast<wunet_half*>(smem);          // [2][hi|lo][4][COLS, de-interleaved][8]
     wunet_half* const ws0 = xs0 + 2 * XP * 8;                              // [2][hi|lo][M_REP][TG][4][16][8]
     float* const red = reinterpret_cast<float*>(ws0 + 2 * WP * 8);        // [4 waves][M_REP * 16][2] statistics hand-over
-    float* const coef = red + WUNET_WAVES * M_REP * 32 + 4;                // [a | s][(C8 + 1) * 8]: BatchNorm scale / shift of the operand's channels
+    float* const coef = red + WUNET_WAVES * M_REP * 32 + 4;                // [a | s][C8 * 8]: BatchNorm scale / shift of the operand's channels (x the operand scale)
     const int ER = A.mblocks * M_REP * 16;
-    float* const epi = coef + 2 * (A.C8 + 1) * 8;                          // [bias | eval a | eval s][ER]: the epilogue's per-row constants
+    float* const epi = coef + 2 * A.C8 * 8;                          // [bias | eval a | eval s][ER]: the epilogue's per-row constants
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wunet_uniform(tid >> 6);
     const int cw = wave & 3;                      // MFMA wave / loader wave index
@@ -385,11 +401,11 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
     wunet_h3u_x_scale(A.xb0, A.xb1, xs_, xinv_);
     if (blockIdx.x == 0 && tid == 0 && A.xsc) { A.xsc[0] = xs_; A.xsc[1] = xinv_; }
 
-    // [a | s] x (C8 + 1) groups, times the operand's scale; channels beyond the operand's and the extra group: 0
-    for (int c = tid; c < (A.C8 + 1) * 8; c += 2 * WUNET_THREADS) {
+    // [a | s] x C8 groups, times the operand's scale; channels beyond the operand's: 0
+    for (int c = tid; c < A.C8 * 8; c += 2 * WUNET_THREADS) {
         const bool u = c < A.C0, k = c < A.C0 + A.C1;
         coef[c] = xs_ * (u ? A.a0[c] : k ? A.a1[c - A.C0] : 0.0f);
-        coef[(A.C8 + 1) * 8 + c] = xs_ * (u ? A.s0[c] : k ? A.s1[c - A.C0] : 0.0f);
+        coef[A.C8 * 8 + c] = xs_ * (u ? A.s0[c] : k ? A.s1[c - A.C0] : 0.0f);
     }
     // (from global memory they were one memory round trip per work item with the matrix pipe idle: this kernel has no second block on the
     //  CU to fill it)
@@ -437,9 +453,11 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
     case 2: wunet_dma16m<2 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
     case 3: wunet_dma16m<3 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
     case 4: wunet_dma16m<4 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
-    default: wunet_dma16m<5 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                               \
+    case 5: wunet_dma16m<5 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    case 6: wunet_dma16m<6 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                                \
+    default: wunet_dma16m<7 * WPM * 16>(RUN_, VOFF_, wunet_lds_uniform(LB_)); break;                               \
     }
-        static_assert(M_REP <= 3, "six runs per W sub-tile");
+        static_assert(M_REP <= 4, "eight runs per W sub-tile");
         // Tile t's loads are issued three stages before the MFMA waves need it: in stage t the loaders convert tile t + 1 (loaded two
         // stages ago) into the other buffer while the loads of tiles t + 2 and t + 3 are in flight - memory latency under load (2 - 3 us)
         // is several stage times.  R0 / R1 / R2 rotate by unrolling, not by moves.

@@ -162,7 +162,7 @@ int launch_conv_h3u(const ConvH3uArgs& a0, int mrep, int mtiles_p, int kch, hipS
     a.NS = (a.C8 + 3) / 4;
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     a.trace = g_h3_trace ? g_h3_trace + (1 << 20) : nullptr;      // (behind conv_h3d_kernel's region of the caller's trace buffer; written by -DWUNET_H3U_TRACE builds only)
-    const size_t smem = (size_t)(2 * 2 * 4 * 272 + 2 * 2 * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4 + 2 * (a.C8 + 1) * 8 + 3 * mtiles_p * 16) * sizeof(float);   // (red, the coefficient table (one all-zero group more), the epilogue constants)
+    const size_t smem = (size_t)(2 * 2 * 4 * 272 + 2 * 2 * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4 + 2 * a.C8 * 8 + 3 * mtiles_p * 16) * sizeof(float);   // (red, the coefficient table, the epilogue constants)
     const int nitems = a.ntiles * a.mblocks;
     int gx = h3_grid_cap() / 2;                  // one block per CU
     if (gx > nitems) gx = nitems;

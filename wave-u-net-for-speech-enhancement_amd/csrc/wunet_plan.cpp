@@ -368,10 +368,10 @@ void layout_workspace(wunet_ctx* c)
             // whose conv is bound by operand bytes, not by the matrix pipe.  WUNET_H3U = "<eval min L>,<train min L>" (0: off), read
             // when the context is planned
             {
-                int u_eval = 2048, u_train = 0;
+                int u_eval = 512, u_train = 0;       // (batch 64: 2048 / 1024 1.565 / 1.572 ms, 512 / 256 1.554 / 1.555, off 1.88; training: ties, profiles/r5_h3u_eval_threshold_sweep.txt)
                 if (const char* e = getenv("WUNET_H3U")) sscanf(e, "%d,%d", &u_eval, &u_train);
                 const bool can = l.h3f && l.h3x && l.kind == LK_UPCAT && l.taps == 5 && l.L >= 256 && l.c0 % 8 == 0 && l.cin % 8 == 0 &&
-                                 l.h3f_mrep <= 3 && l.f.ksplit == 1 && !c->bf && !c->padded;
+                                 l.h3f_mrep <= 4 && l.f.ksplit == 1 && !c->bf && !c->padded;
                 l.h3u = (can && u_eval > 0 && l.L >= u_eval) ? 1 : 0;
                 l.h3u_train = (can && u_train > 0 && l.L >= u_train) ? 1 : 0;
             }
