@@ -3,6 +3,7 @@
 C oracle on tiny networks.  This validates index math, the MFMA lane layout as documented in the
 CDNA4 guide, workspace planning and the autograd plumbing without a GPU; the `-m gpu` tests repeat
 the comparison on real hardware."""
+import ctypes
 import importlib
 
 import numpy as np
@@ -266,10 +267,11 @@ def test_fused_adam_matches_torch(emu_engine):
         assert (sd_ref["state"][k]["exp_avg_sq"] - sd_our["state"][k]["exp_avg_sq"]).abs().max().item() < 1e-7
 
 
-@pytest.mark.parametrize("n,ci,B,T,grid", [(2, 24, 2, 1024, "8"),      # persistent blocks walk two items each; chunks with both branches
-                                           (3, 24, 1, 2048, "4"),      # three decoder levels on the kernel, 8 / 4 / 2 tiles per row
-                                           (2, 16, 3, 512, "")])       # 16-channel groups: one branch per chunk pair, a half-empty last chunk
-def test_fused_operand_conv_matches_the_two_kernel_path(monkeypatch, n, ci, B, T, grid):
+@pytest.mark.parametrize("n,ci,B,T,grid,order", [(2, 24, 2, 1024, "8", ""),      # persistent blocks walk two items each; chunks with both branches
+                                                 (3, 24, 1, 2048, "4", ""),      # three decoder levels on the kernel, 8 / 4 / 2 tiles per row
+                                                 (2, 16, 3, 512, "", ""),        # 16-channel groups: one branch per chunk pair, a half-empty last chunk
+                                                 (2, 24, 2, 1024, "8", "4")])    # four accumulator rows per wave (conv_h3u_kernel<4>: eight runs per W sub-tile)
+def test_fused_operand_conv_matches_the_two_kernel_path(monkeypatch, n, ci, B, T, grid, order):
     """conv_h3u_kernel (wunet_h3u.h: the decoder conv whose loader waves build the operand from the producers' raw conv outputs - BatchNorm
     scale / shift, LeakyReLU, ATen's upsample coordinates, concat, split - instead of reading what prep_h3_kernel wrote) against the oracle
     and against prep_h3_kernel + conv_h3d_kernel, in eval mode (its product use) and in training mode (statistics rows, the operand written
@@ -280,31 +282,44 @@ def test_fused_operand_conv_matches_the_two_kernel_path(monkeypatch, n, ci, B, T
     monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")
     if grid:
         monkeypatch.setenv("WUNET_H3_GRID", grid)
+    if order:
+        monkeypatch.setenv("WUNET_H3_ORDER", order)
     noisy, clean = plan.golden_batch(B, T, 0)
     sd = plan.golden_state(n, ci, 0)
     ref_e = c_oracle.step(sd, noisy, clean, n, ci, False, "mse", want_grads=False, precision="f64")
     ref_t = c_oracle.step(sd, noisy, clean, n, ci, True, "mse", precision="f64")
 
+    ran = {}
+
     def run(h3u, training):
         monkeypatch.setenv("WUNET_H3U", h3u)
         eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
         m, _, _ = _build(n, ci, eng)
-        if not training:
-            m.eval()
-            with torch.no_grad():
-                return m(torch.from_numpy(noisy)).numpy(), None
-        m.train()
-        crit = pkg_loss.mse_loss()
-        crit._engine_override = eng
-        out = m(torch.from_numpy(noisy))
-        crit(torch.from_numpy(clean), out).backward()
-        return out.detach().numpy(), {k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+        eng.lib.wunet_profile_enable(1)                  # (emulator: the names of the annotated kernels that ran)
+        try:
+            if not training:
+                m.eval()
+                with torch.no_grad():
+                    return m(torch.from_numpy(noisy)).numpy(), None
+            m.train()
+            crit = pkg_loss.mse_loss()
+            crit._engine_override = eng
+            out = m(torch.from_numpy(noisy))
+            crit(torch.from_numpy(clean), out).backward()
+            return out.detach().numpy(), {k: p.grad.numpy().copy() for k, p in m.named_parameters()}
+        finally:
+            buf = ctypes.create_string_buffer(1 << 16)
+            eng.lib.wunet_profile_collect(buf, len(buf))
+            eng.lib.wunet_profile_enable(0)
+            ran[(h3u, training)] = [ln.split("\t")[0] for ln in buf.value.decode().splitlines()]
 
     e_old, _ = run("0,0", False)
     e_new, _ = run("256,256", False)
     assert np.abs(e_new - ref_e["out"]).max() < 2e-6 and np.abs(e_new - e_old).max() < 1e-6
-    if ci == 24:
-        assert not np.array_equal(e_new, e_old)     # (really another kernel: these layers' K tails vs whole chunks add in another order)
+    want = "conv_h3u_kernel<4>" if order == "4" else "conv_h3u_kernel<"
+    assert any(k.startswith(want) for k in ran[("256,256", False)]) and not any("h3u" in k for k in ran[("0,0", False)]), ran
+    if ci == 24 and not order:
+        assert not np.array_equal(e_new, e_old)     # (these layers' K tails vs whole chunks add in another order)
     t_old, g_old = run("0,0", True)
     t_new, g_new = run("256,256", True)
     assert np.abs(t_new - ref_t["out"]).max() < 2e-5
@@ -315,6 +330,7 @@ def test_fused_operand_conv_matches_the_two_kernel_path(monkeypatch, n, ci, B, T
         scale = max(np.abs(r).max(), 1e-6)
         assert np.abs(g_new[k] - r).max() < 3e-4 * scale + 1e-6, (k, np.abs(g_new[k] - r).max(), scale)
         assert np.abs(g_new[k] - g_old[k]).max() < 1e-4 * scale + 1e-7, k
+    assert any(k.startswith(want) for k in ran[("256,256", True)]), ran
 
 
 @pytest.mark.parametrize("n,ci,B,T,grid", [(3, 24, 2, 2048, ""), (4, 16, 3, 4096, "8"), (3, 20, 2, 1024, "")])

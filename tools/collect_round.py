@@ -18,8 +18,8 @@ for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.
                  ("serial_kernel_stats.csv", "serial_bench_kernel_stats.csv"), ("forward_bench.json", "forward_bench.json"),
                  ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"), ("next_rows_bench.txt", "next_rows_bench.txt"),
                  ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt"),
-                 ("h3u_sweep.txt", "h3u_eval_threshold_sweep.txt"), ("h3u_ablation.txt", "h3u_ablation.txt"), ("h3u_stage_timeline.txt", "h3u_stage_timeline.txt"),
-                 ("round4_vs_round5_same_box.txt", "round4_vs_round5_same_box.txt"), ("evop_ab.txt", "evop_eval_ab.txt"), ("git_state.txt", "git_state.txt")):
+                 ("h3u_sweep.txt", "h3u_threshold_sweep.txt"), ("h3u_ablation.txt", "h3u_ablation.txt"), ("h3u_stage_timeline.txt", "h3u_stage_timeline.txt"),
+                 ("round4_vs_round5_same_box.txt", "round4_vs_round5_same_box.txt"), ("evop_ab.txt", "evop_eval_ab.txt"), ("git_state.txt", "git_state.txt"), ("gpu_tests.txt", "gpu_tests.txt")):
     if not os.path.exists(os.path.join(F, src)):
         continue
     stamp = os.path.join(F, "git_state.txt")        # (gpurun merges into gpurun_out/ without deleting: leftovers of an earlier round are older than this run's stamp)

@@ -11,6 +11,10 @@ if [ ! -f $R/tools/_git_state ] || [ "$(cut -d' ' -f3 $R/tools/_git_state)" != "
     echo "refused: tools/_git_state missing or not these sources - start the measurement with tools/run_measure_round.sh" >&2; exit 2
 fi
 cp $R/tools/_git_state $O/git_state.txt
+if [ -z "$PMC_ONLY" ]; then      # the -m gpu suite and the smoke hook on the sources the set is taken from (the summary lines go to profiles/)
+    ( cd $R && timeout 900 python -m pytest tests -m gpu -q > $O/gpu_tests_full.log 2>&1; grep -E "^[0-9]+ (passed|failed)|passed|failed|error" $O/gpu_tests_full.log | tail -5 > $O/gpu_tests.txt
+      python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep smoke >> $O/gpu_tests.txt; cat $O/gpu_tests.txt )
+fi
 cd /tmp; export TMPDIR=/tmp
 pmc_pass() {   # <name> <bench args...>: FETCH_SIZE and WRITE_SIZE passes of 3 steps (1 warm-up + 2) -> $O/pmc_raw_<name>.json
     local name=$1; shift
@@ -77,8 +81,8 @@ cd $R
 timeout 300 python tools/next_rows_bench.py 2>/dev/null | grep -v amdgpu > $O/next_rows_bench.txt       # f1 / f3 / f4 of SURVEY.md section 8(f)
 # round 5: conv_h3u_kernel (eval decoder levels) - threshold sweep, ablation (tools/h3u_ablation.sh build first, in the container), stage timeline
 # (tools/build_h3u_trace.sh first); the previous round's library against this one on this box (tools/_lib_round4.so)
-timeout 300 bash tools/h3u_sweep.sh > $O/h3u_sweep.txt 2>&1
-ls tools/_lib_u16.so > /dev/null 2>&1 && H3U=8192,0 timeout 300 bash tools/h3u_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/h3u_ablation.txt $O/h3u_ablation.txt
+{ echo "conv_h3u_kernel from different minimum levels, WUNET_H3U=<eval min L>,<train min L> (0: prep_h3_kernel + conv_h3d_kernel); eval forward and training step, batch 64, one box, first and last arm of each group the same (tools/h3u_ab.sh)"; EVAL_ARMS="0,0 2048,0 1024,0 512,0 256,0 0,0" TRAIN_ARMS="512,0 512,4096 512,2048 512,1024 512,512 512,0" timeout 500 bash tools/h3u_ab.sh; } > $O/h3u_sweep.txt 2>&1
+ls tools/_lib_u64.so > /dev/null 2>&1 && H3U=8192,0 timeout 300 bash tools/h3u_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/h3u_ablation.txt $O/h3u_ablation.txt
 [ -f tools/_lib_trace.so ] && timeout 120 python tools/h3u_trace.py 2>/dev/null | grep -v amdgpu > $O/h3u_stage_timeline.txt
 [ -f tools/_lib_round4.so ] && timeout 400 bash tools/round_vs_round.sh > $O/round4_vs_round5_same_box.txt 2>&1
 { for rep in 1 2; do for v in "" 1; do if [ -z "$v" ]; then unset WUNET_NO_EVOP; else export WUNET_NO_EVOP=1; fi

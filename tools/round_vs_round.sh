@@ -1,8 +1,8 @@
 #!/bin/bash
 # usage (GPU box): tools/round_vs_round.sh        - the previous round's library (tools/_lib_round4.so: built from its final commit by
 # `git worktree add /tmp/wt 0a4c048 && make -C /tmp/wt/<pkg>/csrc`) against this round's on ONE box, alternating: training step (100 graph
-# replays) and eval forward (50 forwards), both libraries through the ctypes binding.  The boxes of the pool differ (and came in two clock
-# states in round 5): only this comparison says what the CODE changed.
+# replays) and eval forward (50 forwards), both libraries through the ctypes binding.  The boxes of the pool differ by a few per cent:
+# only this comparison says what the CODE changed.
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 PKG=wave-u-net-for-speech-enhancement_amd
 for rep in 1 2 3; do for lib in round4 round5; do
