@@ -51,6 +51,7 @@ struct ConvH3Args {
     int NS, NFS;                                  // conv_h3d_kernel: K stages of the pack, the first NFS of them full (TG taps of a chunk); the rest: K tail
     int ntiles, mblocks;                          // grid.x = ntiles * mblocks blocks
     int stages_per_split;                         // grid.y splits of the K stages (1 split: all of them)
+    int epi_eval;                                 // the block's LDS table of per-row constants also holds ev_a / ev_s (eval mode, where it fits two blocks per CU)
     size_t split_stride;                          // floats between the partial results of two splits
     // EVOP (eval mode, an encoder level whose consumer is the next encoder level; conv_h3d_kernel<.., EVOP = true>): the epilogue also
     // writes the NEXT layer's split operand - LeakyReLU(a z + s) at the even samples, scaled, hi / lo - into op_h / op_l

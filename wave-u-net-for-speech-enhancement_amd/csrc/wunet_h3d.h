@@ -47,6 +47,11 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS, de-interleaved][8]
     wunet_half* ws = xs + XP * 8;                                      // [hi|lo][M_REP][TG][4][16][8]
     float* red = reinterpret_cast<float*>(ws + WP * 8);                // [4 waves][M_REP * 16][2] statistics hand-over, + 4 maxima
+    // un-segmented tiles (the levels of 256 samples and more): [bias | eval a | eval s][ER], the epilogue's per-row constants, once per block
+    // instead of one global round trip per work item (the eval parts only where A.epi_eval says they fit)
+    constexpr bool EPI_LDS = NSEG == 1;
+    float* const epi = red + WUNET_WAVES * M_REP * 32 + 4;
+    const int ER = A.mblocks * M_REP * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
     const int L = A.L;
@@ -166,6 +171,15 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     constexpr bool KT = WUNET_H3D_HAS_TAIL(M_REP, NSEG);
     const int nfs = KT ? A.NFS : 0x7fffffff, tch = nfs / NTG;        // full stages (TG taps of a chunk of 4 channel groups); the tail stages' chunk
     constexpr int NTT = (TAPS + 3) / 4;            // steps of a tail stage
+    // the epilogue's per-row constants once per block, not one global round trip per work item; the un-scale of operand and weights
+    // (two powers of two: their product is exact) likewise
+    for (int c = threadIdx.x; EPI_LDS && c < ER; c += WUNET_THREADS) {
+        const bool in = c < A.Cout;
+        epi[c] = (in && A.bias && gridDim.y == 1) ? A.bias[c] : 0.0f;
+        if (A.epi_eval) { epi[ER + c] = in ? A.ev_a[c] : 0.0f; epi[2 * ER + c] = in ? A.ev_s[c] : 0.0f; }
+    }
+    const float inv12 = (A.sc ? A.sc[1] : 1.0f) * (A.sc2 ? A.sc2[1] : 1.0f);
+    if (EPI_LDS) wunet_wait_lds_barrier();
     int stamp = 0;
     float amax_run = 0.0f;                          // eval mode: the block's running maximum of the activation bound over its work items
     float op_scale = 1.0f;                          // EVOP: scale of the consumer's operand (ConvH3Args: from the rigorous bound of this layer's activation)
@@ -301,7 +315,6 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         // ---- epilogue (conv_h3_kernel's): un-scale, bias, store, BN statistics of the bias-free conv; a K split stores its
         // bias-free partial sum (statistics then come from the reduce kernel).  The DMAs of the next item's first stage are in flight.
         wunet_setprio(0);
-        const float inv = A.sc ? A.sc[1] : 1.0f, inv2 = A.sc2 ? A.sc2[1] : 1.0f;
         float* outp = A.out + (size_t)blockIdx.y * A.split_stride;
         const int bo = b + lseg;
         float amax = 0.0f;
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = (mt0 + mt) * 16 + q * 4 + r;
-                bvs[mt][r] = (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
+                bvs[mt][r] = EPI_LDS ? epi[co] : (A.bias && !split && co < A.Cout) ? A.bias[co] : 0.0f;
             }
         // row (mt, r) of this lane: prow + (mt * 16 + r) * L  (uniform strides: no 64-bit multiply per row)
         float* const prow = outp + ((size_t)bo * A.Cout + mt0 * 16 + q * 4) * L + (l0 + ll0);
@@ -329,8 +342,8 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
         _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt)                                                      \
             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
                 const int co = (mt0 + mt) * 16 + q * 4 + r;                                                       \
-                eas[mt][r] = co < A.Cout ? A.ev_a[co] : 0.0f;                                                     \
-                ess[mt][r] = co < A.Cout ? A.ev_s[co] : 0.0f;                                                     \
+                eas[mt][r] = (EPI_LDS && A.epi_eval) ? epi[ER + co] : co < A.Cout ? A.ev_a[co] : 0.0f;            \
+                ess[mt][r] = (EPI_LDS && A.epi_eval) ? epi[2 * ER + co] : co < A.Cout ? A.ev_s[co] : 0.0f;        \
             }                                                                                                     \
     }                                                                                                             \
     _Pragma("unroll") for (int mt = 0; mt < M_REP; ++mt) {                                                        \
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             const float bv = bvs[mt][r];                                                                          \
             wunet_f4 o;                                                                                           \
             _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                    \
-                const float vv = acc[mt][nt][r] * inv * inv2;                                                     \
+                const float vv = acc[mt][nt][r] * inv12;                                                     \
                 if (STATS_) { s1[r] += vv; s2[r] = fmaf(vv, vv, s2[r]); }                                                    \
                 o[nt] = vv + bv;                                                                                  \
             }                                                                                                     \

@@ -97,7 +97,7 @@ struct LayerPlan {
 // single-op entry points, so a geometry gets the same kernel instantiation either way.
 struct H3ConvPlan { int mrep, mtp, nch, sps, ksplit, ntiles, ntt; };
 H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* order_env, int bf = 0);
-size_t h3d_smem(int nseg, int mrep, int bf);          // dynamic LDS of a conv_h3d_kernel block
+size_t h3d_smem(int nseg, int mrep, int bf, int mtp, int eval);          // dynamic LDS of a conv_h3d_kernel block
 int h3d_blocks_per_cu(int nseg, int mrep, int bf);   // resident blocks per CU at that size
 int h3_stage_count(int kch, int taps, int ntt);
 void plan_h3_wgrad(LayerPlan& l, int B);

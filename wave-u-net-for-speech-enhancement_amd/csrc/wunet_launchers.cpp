@@ -137,7 +137,9 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
     snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)) + (op ? 2.0 * posn * rows : 0.0));
-    const size_t smem = h3d_smem(nseg, mrep, bf);
+    // (eval: BatchNorm scale / shift beside the bias in the block's table of per-row constants unless that costs the second block of a CU)
+    a.epi_eval = (xrows && nseg == 1 && 2 * h3d_smem(nseg, mrep, bf, mtiles_p, 1) <= 160u * 1024u) ? 1 : 0;
+    const size_t smem = h3d_smem(nseg, mrep, bf, mtiles_p, a.epi_eval);
     const int nitems = a.ntiles * a.mblocks;
     // resident blocks: two per CU, one for the 16-segment tile (96 KB); a K-split layer whose items x splits fit them runs one item per block
     int gx = h3_grid_cap() / 2 * h3d_blocks_per_cu(nseg, mrep, bf) / ksplit;

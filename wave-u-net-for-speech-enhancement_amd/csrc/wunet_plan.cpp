@@ -236,13 +236,16 @@ size_t h3w_part_stride(const LayerPlan& l)
 
 // dynamic LDS of one conv_h3d_kernel block: x tile [planes][4][NSEG * (256 / NSEG + 16)] + W sub-tile [planes][M_REP][5][64] pieces of 16 bytes
 // + the statistics hand-over
-size_t h3d_smem(int nseg, int mrep, int bf)
+// (un-segmented tiles: + the epilogue's per-row constants - bias, in eval mode also the BatchNorm scale / shift - of the mtp * 16 padded rows)
+size_t h3d_smem(int nseg, int mrep, int bf, int mtp, int eval)
 {
     const int npl = bf ? 1 : 2;
-    return (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16 + (size_t)(WUNET_WAVES * mrep * 32 + 4) * sizeof(float);
+    return (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16
+         + (size_t)(WUNET_WAVES * mrep * 32 + 4 + (nseg == 1 ? (eval ? 3 : 1) * mtp * 16 : 0)) * sizeof(float);
 }
-// blocks of that size a CU holds (launch bounds: two; the 16-segment tile's 96 KB: one)
-int h3d_blocks_per_cu(int nseg, int mrep, int bf) { return 2 * h3d_smem(nseg, mrep, bf) <= 160u * 1024u ? 2 : 1; }
+// blocks of that size a CU holds (launch bounds: two; the 16-segment tile's 96 KB: one) - the table of constants never costs the second block
+// (launch_conv_h3 leaves the eval part in global memory where it would)
+int h3d_blocks_per_cu(int nseg, int mrep, int bf) { return 2 * h3d_smem(nseg, mrep, bf, 0, 0) <= 160u * 1024u ? 2 : 1; }
 
 // conv_h3d_kernel split-K of the levels with fewer work items than resident blocks: the K stages are split so that ONE round of
 // resident blocks covers the layer, every block with (nearly) the same number of stages.  Round 4's block start / end times
