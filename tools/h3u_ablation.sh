@@ -1,6 +1,6 @@
 #!/bin/bash
 # What bounds conv_h3u_kernel: the kernel rebuilt with parts compiled out (-DWUNET_H3U_ABL=<bits>, wunet_h3u.h), the eval forward timed per variant.
-#   bits: 1 no prefetch loads   2 no conversion arithmetic   4 no MFMAs   8 no W DMA   16 no conversion at all (no LDS writes)   32 no fragment reads, no MFMAs
+#   bits: 1 no prefetch loads   4 no MFMAs   8 no W DMA   16 no conversion at all (no LDS writes)   32 no fragment reads, no MFMAs
 #         64 the loads stay alive (their registers are summed) but nothing is converted   128 conversion without its LDS writes
 #   e.g. 100 = 64 + 32 + 4: the memory pipeline alone;  36: the loader waves alone;  64: loads in flight but nothing converted (the MFMA waves + the memory pipeline)
 #   (16 WITHOUT 1 is not a valid build since the prefetch loads come from inline asm: with nothing reading their destination registers hipcc hands

@@ -14,10 +14,15 @@
 // and W sub-tile are double-buffered: ONE workgroup barrier per stage (the buffer a stage reads was completed before the
 // barrier; the buffer the loaders fill was last read in the previous stage).
 // No K tail (the forward pack of such a layer is built without one), no K split (levels >= 256 samples only).
+// The loader waves are ISSUE bound (a wave issues one instruction per ~4.4 cycles whatever the unit; profiles/r5_h3u_loader_diet.txt): their
+// loop is kept lean - stage cursors instead of divisions, scalar-base loads, per-item interpolation weights, the row-edge selects in an
+// instantiation only the first tile of a row takes, the operand scale folded into the BatchNorm coefficients, nothing for empty channel
+// groups - and what remains of a stage is mostly the 17 memory instructions per wave (~100 cycles each at the CU's shared address path).
 #pragma once
 #include "wunet_h3.h"
-// WUNET_H3U_ABL: ablation builds of tools/h3u_ablation.sh (parts of the kernel compiled out: 1 no global loads, 2 no conversion arithmetic,
-// 4 no MFMAs, 8 no W DMA, 16 no conversion at all (no LDS writes), 32 no fragment reads and no MFMAs); 0 in the product
+// WUNET_H3U_ABL: ablation builds of tools/h3u_ablation.sh (parts of the kernel compiled out: 1 no global loads, 4 no MFMAs, 8 no W DMA,
+// 16 no conversion at all (no LDS writes), 32 no fragment reads and no MFMAs, 64 the loads kept alive but nothing converted, 128 no LDS writes);
+// 0 in the product
 #ifndef WUNET_H3U_ABL
 #define WUNET_H3U_ABL 0
 #endif
