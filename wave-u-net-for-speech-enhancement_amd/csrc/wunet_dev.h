@@ -221,8 +221,10 @@ __device__ __forceinline__ void wunet_pow2_scale(float bound, float& s, float& i
 // scale derived from it stays defined).  Order independent: the result does not depend on which block arrives when.
 __device__ __forceinline__ void wunet_atomic_absmax(float* slot, float v)
 {
-    const unsigned u = wunet_fbits(v) & 0x7fffffffu;
-    atomicMax(reinterpret_cast<unsigned*>(slot), u < 0x7f800000u ? u : 0x7f7fffffu);
+    const unsigned u = wunet_fbits(v) & 0x7fffffffu, w = u < 0x7f800000u ? u : 0x7f7fffffu;
+    // (a maximum only grows: a block whose value is not above what the slot already holds has nothing to add - one plain load instead of
+    //  one more atomic on the ONE address every block of the launch goes to)
+    if (w > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(reinterpret_cast<unsigned*>(slot), w);
 }
 #define WUNET_THREADS 256
 #define WUNET_WAVES 4
