@@ -341,7 +341,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         } else if (split) {
             // sum the z-slices (+bias -> z) and reduce the BN statistics; short levels finish BN in the same launch
             const long long pos = (long long)c->B * l.L;
-            int rs = (int)(pos / 2048);
+            // (eval: every block ends in a block-wide maximum and an atomic on one address - half as many blocks: eval forward 1.470 -> 1.445 ms,
+            //  one block per channel the same, twice as many 1.53 -> 1.57; training 2048 / 4096 / 8192 positions per block: 5.166 / 5.152 /
+            //  5.148 ms, within the noise and another summation order - left alone; profiles/r5_small_ab.txt)
+            int rs = (int)(pos / (training ? 2048 : 4096));
             if (rs < 1) rs = 1;
             if (rs > 64) rs = 64;
             b.rows = rs;
