@@ -83,3 +83,31 @@ def test_loader_prefetch_registers_are_untouched_until_their_wait():
         pytest.skip("no hipcc")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_h3u_isa.py")], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "3 kernels checked, 0 problems" in p.stdout, p.stdout[-2000:] + p.stderr[-500:]
+
+
+def test_the_isa_checker_sees_a_touched_prefetch_register():
+    """The checker must FAIL on what it guards against: the same ISA with one instruction planted that (a) overwrites a prefetch load's destination
+    right behind the load, (b) reads it just before the stage barrier that does not cover it yet - the compiler-inserted copy / temporary re-use
+    that tools/check_h3u_isa.py exists to catch."""
+    import importlib.util
+    import os
+    import re
+    from conftest import ROOT
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    spec = importlib.util.spec_from_file_location("check_h3u_isa", os.path.join(ROOT, "tools", "check_h3u_isa.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    name, lines = next(iter(chk.kernels(chk.compile_isa())))          # (one instantiation is enough)
+    assert chk.check(name, lines) == []
+    barriers = [i for i, ln in enumerate(lines) if re.search(r"s_waitcnt vmcnt\(10\) lgkmcnt\(0\)", ln)]
+    # a prefetch load of the steady loop: an asm global_load_dwordx4 behind the first stage barrier
+    load = next(i for i in range(barriers[0], len(lines)) if re.match(r"\s*global_load_dwordx4 v\[(\d+):\d+\], v\d+, s\[", lines[i]))
+    reg = int(re.match(r"\s*global_load_dwordx4 v\[(\d+):", lines[load]).group(1))
+    overwritten = lines[:load + 1] + [f"\tv_mov_b32_e32 v{reg}, 0"] + lines[load + 1:]
+    errs = chk.check(name, overwritten)
+    assert errs and f"v_mov_b32_e32 v{reg}, 0" in errs[0], errs[:2]
+    nxt = next(b for b in barriers if b > load)                        # the barrier that ends the load's own stage: the data need not be there yet
+    read_early = lines[:nxt] + [f"\tv_add_f32_e32 v{reg + 1}, v{reg + 1}, v{reg + 1}"] + lines[nxt:]
+    errs = chk.check(name, read_early)
+    assert errs and "v_add_f32_e32" in errs[0], errs[:2]

@@ -215,12 +215,16 @@ def check(name, lines):
     return errs
 
 
-def main():
+def compile_isa():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "h3u.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I.", "-I../../include",
                         "-Wno-unused-result", "-Wno-unused-value", "-S", "--cuda-device-only", "h3u_inst.cpp", "-o", out], cwd=CSRC, check=True)
-        asm = open(out).read()
+        return open(out).read()
+
+
+def main():
+    asm = compile_isa()
     errs, n = [], 0
     for name, lines in kernels(asm):
         n += 1
