@@ -68,12 +68,28 @@ __device__ __forceinline__ void wunet_loader_barrier(int younger)
 #endif
 }
 
+// The per-item barrier of the statistics hand-over (the MFMA waves' row sums go through LDS once per work item): same wait, but it does
+// NOT end a stage - the operands are written in the other order (`lgkmcnt(0) vmcnt(10)`) so that tools/check_h3u_isa.py, which counts
+// STAGE barriers behind a prefetch load, tells the two kinds apart in the ISA.
+__device__ __forceinline__ void wunet_loader_stats_barrier(int younger)
+{
+#ifdef WUNET_EMU
+    (void)younger;
+    emu::block_barrier();
+#else
+    if (younger >= 10) asm volatile("s_waitcnt lgkmcnt(0) vmcnt(10)\n\ts_barrier" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_barrier" ::: "memory");
+    wunet_sched_fence();
+#endif
+}
+
 // ---- loader side.  Loader wave `cw` builds channel group ch*4 + cw of the x tile [hi|lo][4][COLS, de-interleaved][8]: the 260 columns
 // 6 .. 265 a 5-tap fragment reads (column c = sample l0 - 8 + c).  Lane k owns the four samples P .. P+3, P = l0 - 2 + 4k, of the
 // group's 8 channels: ONE 16-byte load per channel - skip branch: the samples themselves; upsampled branch: the four source samples
 // wb .. wb+3, wb = (P-2)/2, which are exactly what ATen's coordinates of the four outputs touch ((i0, i1) = (wb, wb+1), (wb+1, wb+2),
-// (wb+1, wb+2), (wb+2, wb+3); checked against the exact fp32 coordinates per lane, any other outcome - the clamped ends of a row -
-// takes the general path) - so a lane activates 4 source values per channel instead of 8 and a tile costs 8 load instructions per
+// (wb+1, wb+2), (wb+2, wb+3): the planner checks exactly that on the host for the layer's length - wunet_plan.cpp up_pairs_regular,
+// ATen's fp32 coordinates over the whole row - and a length that fails it keeps prep_h3_kernel + conv_h3d_kernel; the row's first
+// outputs take the EDGE instantiation's selects) - so a lane activates 4 source values per channel instead of 8 and a tile costs 8 load instructions per
 // wave, few enough to keep THREE tiles in flight (WunetH3uRaw: 34 registers).  The last 4 columns (262 .. 265) are one value per lane
 // of lanes 0 .. 31.  Two steps: wunet_h3u_issue (the loads) and, stages later, wunet_h3u_convert (prep_h3_kernel's arithmetic:
 // BatchNorm scale / shift, LeakyReLU, ATen's upsample weights, scale, split; LDS writes; in training also the operand's copy in HBM).
@@ -514,7 +530,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
            stages (>= 2 M_REP + 1 per wave and stage); with the operand's copy to HBM in the queue as well (training) everything */  \
         if (A.oxh) wunet_vm_wait<0>(); else wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                              \
         wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, K, coef, WUNET_H3U_SUBPTR);          \
-        if (want_stats && tn.ch == 0) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                 \
+        if (want_stats && tn.ch == 0) wunet_loader_stats_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);           \
         ++t;                                                                                                       \
     }
         int t = 0;
@@ -527,7 +543,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         }
         // the last stage: nothing left to prepare
         wunet_loader_barrier(0);
-        if (want_stats) wunet_loader_barrier(0);
+        if (want_stats) wunet_loader_stats_barrier(0);
 #undef WUNET_H3U_LOADER_STAGE
 #undef WUNET_H3U_DMA_W
 #undef WUNET_H3U_DMA_PIECE

@@ -102,6 +102,7 @@ int h3d_blocks_per_cu(int nseg, int mrep, int bf);   // resident blocks per CU a
 int h3_stage_count(int kch, int taps, int ntt);
 void plan_h3_wgrad(LayerPlan& l, int B);
 size_t h3w_part_stride(const LayerPlan& l);
+bool up_pairs_regular(int Lin);       // the x2 upsample reads the source pairs ((j-1) >> 1, +1) at this length (fp32 coordinates, host check)
 unsigned pack_gx();
 
 }  // namespace wunet_host

@@ -134,6 +134,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     a.trace = g_h3_trace;
+    if (op && (ksplit != 1 || nseg != 1 || !ev_a || !xrows)) return fail(WUNET_E_ARG, "conv_h3d EVOP needs an un-split whole-row eval launch");
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
     snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)) + (op ? 2.0 * posn * rows : 0.0));
@@ -147,7 +148,6 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     if (gx < 8) gx = 8;
     if (gx > nitems) gx = nitems;
     const dim3 grid((unsigned)gx, (unsigned)ksplit);
-    if (op && (ksplit != 1 || nseg != 1 || !ev_a || !xrows)) return fail(WUNET_E_ARG, "conv_h3d EVOP needs an un-split whole-row eval launch");
     const int rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, op != nullptr);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d nseg=%d (rc %d)", taps, mrep, nseg, rc);

@@ -345,6 +345,34 @@ void plan_h3_wgrad(LayerPlan& l, int B)
     l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
 }
 
+// The x2 upsample's source pairs as the fused loaders assume them (conv_h3u_kernel, and the gradient-side kernels that gather through
+// the same pairs): output j >= 1 of a row of Lin source samples reads (i0, i1) = ((j-1) >> 1, i0 + 1) under ATen's fp32 coordinates
+// (wunet_up_coord's arithmetic, restated here on the host with every product rounded to fp32), output 0 reads source 0 with weight
+// 1, and an output whose i0 is the row's last sample has weight exactly 0 on the sample behind the row.  True for every power-of-two
+// length up to 4 M samples; checked per length when a context is planned (cached), and a layer whose length fails it keeps the
+// two-kernel path.
+bool up_pairs_regular(int Lin)
+{
+    static std::mutex lock;
+    static std::map<int, bool> seen;
+    std::lock_guard<std::mutex> g(lock);
+    auto it = seen.find(Lin);
+    if (it != seen.end()) return it->second;
+    bool ok = Lin >= 2;
+    const int Lout = 2 * Lin;
+    const float scale = (float)(Lin - 1) / (float)(Lout - 1);
+    for (int j = 0; ok && j < Lout; ++j) {
+        volatile float src = scale * (float)j;                 // (volatile: the product is rounded to fp32 before it is used)
+        int a = (int)floorf(src);
+        a = a > Lin - 1 ? Lin - 1 : a;
+        float lam = src - (float)a;
+        lam = lam < 0.0f ? 0.0f : (lam > 1.0f ? 1.0f : lam);
+        if (j == 0) ok = a == 0 && lam == 0.0f;
+        else ok = a == ((j - 1) >> 1) && (a < Lin - 1 || lam == 0.0f);
+    }
+    return seen[Lin] = ok;
+}
+
 void layout_workspace(wunet_ctx* c)
 {
     const int B = c->B, T = c->T, ci = c->ci;
@@ -389,9 +417,14 @@ void layout_workspace(wunet_ctx* c)
             // when the context is planned
             {
                 int u_eval = 512, u_train = 2048;    // (batch 64, one box - eval: off 1.87 ms, from 2048 1.567, from 512 1.516; training step: off 5.12 / 5.20, from 2048 or 4096 5.08 / 5.15, from 512 5.17: profiles/r5_h3u_threshold_sweep.txt)
-                if (const char* e = getenv("WUNET_H3U")) sscanf(e, "%d,%d", &u_eval, &u_train);
+                if (const char* e = getenv("WUNET_H3U")) {
+                    int a = 0, b = 0;
+                    const int got = sscanf(e, "%d,%d", &a, &b);
+                    if (got == 2) { u_eval = a; u_train = b; }
+                    else if (got == 1) u_eval = u_train = a;      // one number: both thresholds (WUNET_H3U=0 turns the kernel off everywhere)
+                }
                 const bool can = l.h3f && l.h3x && l.kind == LK_UPCAT && l.taps == 5 && l.L >= 256 && l.c0 % 8 == 0 && l.cin % 8 == 0 &&
-                                 l.h3f_mrep <= 4 && l.f.ksplit == 1 && !c->bf && !c->padded;
+                                 l.h3f_mrep <= 4 && l.f.ksplit == 1 && !c->bf && !c->padded && up_pairs_regular(l.L / 2);
                 l.h3u = (can && u_eval > 0 && l.L >= u_eval) ? 1 : 0;
                 l.h3u_train = (can && u_train > 0 && l.L >= u_train) ? 1 : 0;
             }

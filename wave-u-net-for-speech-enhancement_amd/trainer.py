@@ -29,8 +29,14 @@ from .optim import FusedAdam
 from .parallel import GradSync
 
 GRAPH_WARMUP_STEPS = 3
-MAX_RECAPTURES = 3           # hyper-parameter changes in a row (each at most RECAPTURE_RESET replays after the last) before the graph is given up
-RECAPTURE_RESET = 2          # "in a row" = a PER-STEP schedule; a per-epoch scheduler, however short the epoch, keeps its graph
+# A captured step graph is given up for eager launches when MAX_RECAPTURES graphs IN A ROW did not earn their capture back: a graph
+# earns REPLAY_CREDIT_S per replay (what a replay saves over the eager step when the loop synchronises: host launch jitter, 5.27 vs
+# 5.5 ms median at the BASELINE size; back to back the two are level) and costs the measured wall time of its capture + instantiate;
+# fewer than MIN_REPLAYS replays never count as earned.  A schedule that changes lr / betas / eps every step - or every 3 or 20 steps -
+# therefore ends on eager launches after three captures, a per-epoch scheduler over long epochs keeps its graph.
+MAX_RECAPTURES = 3
+MIN_REPLAYS = 16
+REPLAY_CREDIT_S = 0.25e-3
 
 
 class Trainer:
@@ -80,8 +86,9 @@ class Trainer:
         self._graph_sig = None
         self._static = None
         self._eager_steps = 0
-        self._recaptures = 0          # consecutive re-captures forced by a changed lr / betas / eps (a per-step LR schedule)
+        self._recaptures = 0          # consecutive graphs, dropped for a changed lr / betas / eps, that did not earn their capture back
         self._replays = 0
+        self._capture_s = 0.0         # wall time of the live graph's capture
         self.start_epoch = 1
         self.best_score = float("-inf")
         root = Path(os.path.expanduser(config.get("root_dir", "."))).absolute() / config.get("experiment_name", "exp")
@@ -167,12 +174,13 @@ class Trainer:
         if self._graph is not None and self.optimizer.hyper_signature() != self._graph_sig:
             # lr / betas / eps / grad_scale are kernel arguments of the captured Adam step: a scheduler, a manual decay or a
             # load_state_dict with another lr would be ignored by the replay - capture again with the new values.  A schedule that
-            # changes them EVERY step would turn each step into capture + instantiate + one replay (far slower than eager): after
-            # MAX_RECAPTURES changes with at most RECAPTURE_RESET replays in between, the graph is given up for eager launches.
+            # changes them every step (or every few steps) would spend its time in capture + instantiate (far slower than eager):
+            # after MAX_RECAPTURES graphs in a row that did not earn their capture back (see the constants), eager launches.
             self._graph = None
-            self._recaptures = self._recaptures + 1 if self._replays <= RECAPTURE_RESET else 1
+            earned = self._replays >= MIN_REPLAYS and self._replays * REPLAY_CREDIT_S >= self._capture_s
+            self._recaptures = 0 if earned else self._recaptures + 1
             self._replays = 0
-            if self._recaptures > MAX_RECAPTURES:
+            if self._recaptures >= MAX_RECAPTURES:
                 import warnings
                 warnings.warn("Trainer: the optimiser's hyper-parameters change every few steps (a per-step LR schedule?); the captured "
                               "step graph would be rebuilt each time - falling back to eager launches", RuntimeWarning)
@@ -183,7 +191,10 @@ class Trainer:
             if self._eager_steps < GRAPH_WARMUP_STEPS:
                 self._eager_steps += 1
                 return self._eager_step(mixture, clean)
+            import time
+            t0 = time.perf_counter()
             self._capture(mixture, clean)
+            self._capture_s = time.perf_counter() - t0
         if mixture.shape != self._static[0].shape:          # a ragged last batch: eager (same kernels, same numbers)
             loss = self._eager_step(mixture, clean)
             return loss

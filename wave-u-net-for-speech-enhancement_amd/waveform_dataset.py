@@ -73,64 +73,79 @@ def read_wav(path):
     return np.ascontiguousarray(x), rate
 
 
-def sample_fixed_length_data_aligned(data_a, data_b, sample_length):
-    """Reference util/utils.py:101-113: one random window of `sample_length`, the same for both signals."""
-    assert len(data_a) == len(data_b), "Inconsistent dataset length, unable to sampling"
-    assert len(data_a) >= sample_length, f"len(data_a) is {len(data_a)}, sample_length is {sample_length}."
-    start = np.random.randint(len(data_a) - sample_length + 1)
-    return data_a[start:start + sample_length], data_b[start:start + sample_length]
+# ---------------------------------------------------------------------------------------------- the list file and the item contract
+class PairList:
+    """The reference's list file - one "<noisy path><space><clean path>" per line (dataset/waveform_dataset.py:15-29), `offset` lines
+    skipped, then at most `limit` kept - parsed once into records.  Both readers of the format use it: `Dataset` (decode per item,
+    the reference's contract) and `pack_shard` (decode once into a shard)."""
+
+    def __init__(self, list_file, limit=None, offset=0):
+        with open(os.path.abspath(os.path.expanduser(list_file)), "r") as f:
+            rows = [ln.rstrip("\n") for ln in f][offset:]
+        self.rows = rows[:limit] if limit else rows
+
+    def __len__(self):
+        return len(self.rows)
+
+    def pair(self, k):
+        """(noisy path, clean path, item name = the noisy file's stem) of record k."""
+        noisy, clean = self.rows[k].split(" ")
+        return noisy, clean, os.path.splitext(os.path.basename(noisy))[0]
+
+    def decode(self, k):
+        """Both signals of record k as float32 mono + their sample rates + the item name."""
+        noisy, clean, name = self.pair(k)
+        (x, rx), (y, ry) = read_wav(noisy), read_wav(clean)
+        return x, y, rx, ry, name
 
 
-def _read_list(dataset, limit, offset):
-    lines = [line.rstrip("\n") for line in open(os.path.abspath(os.path.expanduser(dataset)), "r")]
-    lines = lines[offset:]
-    if limit:
-        lines = lines[:limit]
-    return lines
+def aligned_window_start(n_a, n_b, sample_length):
+    """First sample of the ONE random window both signals are cut at (util/utils.py:101-113).  The draw is `np.random.randint` over
+    the n - L + 1 valid starts, as in the reference: a run seeded with np.random.seed crops the windows the reference would (the
+    device-side form of the same draw is ShardLoader.draw).  The two assertion texts are the reference's."""
+    assert n_a == n_b, "Inconsistent dataset length, unable to sampling"
+    assert n_a >= sample_length, f"len(data_a) is {n_a}, sample_length is {sample_length}."
+    return int(np.random.randint(n_a - sample_length + 1))
 
 
 class Dataset(data.Dataset):
-    """Reference dataset/waveform_dataset.py:10-67 (constructor arguments, item contract and error messages)."""
+    """Plugin-compatible with the reference's dataset/waveform_dataset.py:10-67: constructor arguments, `mode` check, and the item
+    `(mixture [1, T], clean [1, T], filename)` - a random aligned window of `sample_length` in "train" mode, the whole file in
+    "validation" mode."""
+    MODES = ("train", "validation")
 
     def __init__(self, dataset, limit=None, offset=0, sample_length=16384, mode="train"):
         super().__init__()
-        dataset_list = _read_list(dataset, limit, offset)
-        assert mode in ("train", "validation"), "Mode must be one of 'train' or 'validation'."
-        self.length = len(dataset_list)
-        self.dataset_list = dataset_list
-        self.sample_length = sample_length
-        self.mode = mode
+        assert mode in self.MODES, "Mode must be one of 'train' or 'validation'."
+        self.pairs = PairList(dataset, limit, offset)
+        self.sample_length, self.mode = sample_length, mode
 
     def __len__(self):
-        return self.length
+        return len(self.pairs)
 
     def __getitem__(self, item):
-        mixture_path, clean_path = self.dataset_list[item].split(" ")
-        filename = os.path.splitext(os.path.basename(mixture_path))[0]
-        mixture, _ = read_wav(mixture_path)
-        clean, _ = read_wav(clean_path)
+        mixture, clean, _, _, name = self.pairs.decode(item)
         if self.mode == "train":
-            mixture, clean = sample_fixed_length_data_aligned(mixture, clean, self.sample_length)
-        return mixture.reshape(1, -1), clean.reshape(1, -1), filename
+            s = aligned_window_start(len(mixture), len(clean), self.sample_length)
+            mixture, clean = mixture[s:s + self.sample_length], clean[s:s + self.sample_length]
+        return mixture[None, :], clean[None, :], name
 
 
 # ---------------------------------------------------------------------------------------------- shards
 def pack_shard(dataset, prefix, limit=None, offset=0):
     """Decode every pair of the list file once into `<prefix>.noisy.f32`, `<prefix>.clean.f32` (flat float32) and
     `<prefix>.index.json` ({"names", "starts", "lengths", "sample_rate"}).  Returns the number of items."""
-    lines = _read_list(dataset, limit, offset)
+    pairs = PairList(dataset, limit, offset)
     names, starts, lengths, rate, pos = [], [], [], None, 0
     with open(prefix + ".noisy.f32", "wb") as fn, open(prefix + ".clean.f32", "wb") as fc:
-        for line in lines:
-            mixture_path, clean_path = line.split(" ")
-            mixture, r0 = read_wav(mixture_path)
-            clean, r1 = read_wav(clean_path)
-            assert len(mixture) == len(clean), f"Inconsistent dataset length: {mixture_path}"
-            assert r0 == r1 and (rate is None or rate == r0), f"mixed sample rates: {mixture_path}"
+        for k in range(len(pairs)):
+            mixture, clean, r0, r1, name = pairs.decode(k)
+            assert len(mixture) == len(clean), f"Inconsistent dataset length: {pairs.pair(k)[0]}"
+            assert r0 == r1 and (rate is None or rate == r0), f"mixed sample rates: {pairs.pair(k)[0]}"
             rate = r0
             fn.write(mixture.tobytes())
             fc.write(clean.tobytes())
-            names.append(os.path.splitext(os.path.basename(mixture_path))[0])
+            names.append(name)
             starts.append(pos)
             lengths.append(len(mixture))
             pos += len(mixture)
