@@ -241,6 +241,29 @@ def test_eval_forward_matches_oracle(emu_engine, T):
         assert np.array_equal(m.state_dict()[k].numpy(), before[k]), k
 
 
+@pytest.mark.parametrize("n,ci,B,T", [(2, 8, 2, 96), (4, 8, 2, 384), (3, 8, 2, 768), (2, 8, 4, 192)])
+def test_fp16_split_on_padded_lengths_eval_and_running_statistics(emu_engine_h3, n, ci, B, T):
+    """Lengths m * 2^n on the split path where a conv runs UN-split into the split buffer (conv_reduce_bn_kernel then adds the bias
+    and skips the row padding in the statistics): the conv itself must not add the bias as well.  Behind training-mode BatchNorm a
+    doubled bias cancels in the output and in every gradient - it shows in the eval-mode output (0.03 off before the fix, found on
+    the hardware at 12 levels x 12288 samples) and in the running means the training forward leaves behind."""
+    eng = emu_engine_h3
+    m, sd, _ = _build(n, ci, eng)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, None, n, ci, False, want_grads=False, precision="f64")
+    m.eval()
+    with torch.no_grad():
+        out = m(torch.from_numpy(noisy))
+    assert np.abs(out.numpy() - ref["out"]).max() < 2e-5
+    sd2 = {k: v.copy() for k, v in plan.golden_state(n, ci, 0).items()}
+    c_oracle.step(sd2, noisy, clean, n, ci, True, "mse", precision="f64")          # (updates the running statistics in sd2)
+    m.train()
+    m(torch.from_numpy(noisy))
+    post = m.state_dict()
+    for k in plan.buffer_names(n, ci):
+        assert np.abs(post[k].numpy().astype(np.float64) - sd2[k]).max() < 1e-5, k
+
+
 def test_fused_adam_matches_torch(emu_engine):
     """the fused Adam launch against torch.optim.Adam (train.py:31-35), three steps."""
     optim_mod = importlib.import_module(PKG_NAME + ".optim")

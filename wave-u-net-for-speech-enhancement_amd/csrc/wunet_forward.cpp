@@ -318,7 +318,10 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
             }
             int rc = launch_conv_h3(l.taps, l.h3f_mrep, l.h3f_mtp, l.h3f_sps, xh, xl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wf_hi) + l.h3f_wpk,
-                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk, params[4 * i + 1], sl, sl + 2,
+                                    reinterpret_cast<const wunet_half*>(ws + c->h3_wf_lo) + l.h3f_wpk,
+                                    // (a result that goes through conv_reduce_bn_kernel gets its bias THERE: an un-split launch into the split
+                                    //  buffer - a padded length - added it twice; invisible behind training-mode BatchNorm, 0.03 off in eval mode)
+                                    split ? nullptr : params[4 * i + 1], sl, sl + 2,
                                     split ? ws + c->spart_off : ws + l.z, (training && !split) ? ws + c->stats_off : nullptr, c->B, l.cout,
                                     l.cin, l.h3f_nch, l.L, st, ws + l.xzp, ev_epi ? ws + l.a : nullptr, ev_epi ? ws + l.s : nullptr, ev_epi ? xrows : nullptr, c->bf, l.h3f_ntt,
                                     evop ? &opo : nullptr);
