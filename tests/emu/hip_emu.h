@@ -59,6 +59,7 @@ struct wunet_f4 {
 };
 
 inline wunet_f4 wunet_ld4(const float* p) { wunet_f4 r; std::memcpy(r.v, p, 16); return r; }
+inline wunet_f4 wunet_ld4u(const float* p) { return wunet_ld4(p); }      // (4-byte aligned 16-byte load)
 inline void wunet_st4(float* p, wunet_f4 v) { std::memcpy(p, v.v, 16); }
 inline wunet_f4 wunet_sel4(bool ok, wunet_f4 v) { return ok ? v : wunet_f4{{0.f, 0.f, 0.f, 0.f}}; }
 
@@ -245,6 +246,12 @@ inline double wunet_shfl_xor_d(double v, int mask)
 inline float wunet_row16_sum(float v)
 {
     for (int m = 1; m < 16; m <<= 1) v += wunet_shfl_xor(v, m);
+    return v;
+}
+
+inline float wunet_row16_max(float v)
+{
+    for (int m = 1; m < 16; m <<= 1) v = std::fmax(v, wunet_shfl_xor(v, m));
     return v;
 }
 

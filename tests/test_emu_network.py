@@ -264,6 +264,49 @@ def test_fp16_split_on_padded_lengths_eval_and_running_statistics(emu_engine_h3,
         assert np.abs(post[k].numpy().astype(np.float64) - sd2[k]).max() < 1e-5, k
 
 
+@pytest.mark.parametrize("n,ci,B,T,order", [(2, 24, 2, 1024, ""),        # decoder form (upsampled + skip rows) twice, encoder form once
+                                              (3, 24, 3, 2048, ""),        # c0 = 72: an m-tile whose rows belong to two producers; odd batch
+                                              (3, 20, 2, 1024, "432")])    # four accumulator rows per wave, channel counts that are not multiples of 8
+def test_bn_backward_sums_in_the_data_gradient_epilogue(monkeypatch, n, ci, B, T, order):
+    """conv_h3d_kernel<.., BSUM>: the data gradient's epilogue takes sum g, sum g xhat and the bounds of the layers that produced its rows
+    (through the x2 upsample: against the upsampled mask - the sums are linear in the data gradient; skip rows; decimated rows), those layers
+    run no pass_a_kernel, bn_finalize_bwd_tiles_kernel adds the per-tile rows, gz_split_h3_kernel forms g_z from the data gradients (UP mode:
+    the transposed upsample moved there).  Against the float64 oracle at the bars of test_fp16_split_train_step_matches_oracle, and against
+    the same step with the epilogue off (WUNET_BSUM=0, read when a context is planned): the two take the same sums in another order."""
+    import ctypes
+    from test_scale_robustness import errors, run_step
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")          # (small shapes: un-split data gradients, as at the BASELINE size)
+    if order:
+        monkeypatch.setenv("WUNET_H3D_ORDER", order)
+    sd = plan.golden_state(n, ci, 0)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, True, "mse", precision="f64")
+    got = {}
+    for bs in ("256", "0"):
+        monkeypatch.setenv("WUNET_BSUM", bs)
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
+        eng.lib.wunet_profile_enable(1)
+        out, grads = run_step(eng, sd, n, ci, noisy, clean)
+        buf = ctypes.create_string_buffer(1 << 16)
+        eng.lib.wunet_profile_collect(buf, len(buf))
+        eng.lib.wunet_profile_enable(0)
+        names = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().strip().splitlines()}
+        got[bs] = (out, grads, names)
+        oe, ge = errors(out, grads, ref)
+        assert oe < 2e-5 and ge < 3e-4, (bs, oe, ge)
+    on, off = got["256"][2], got["0"][2]
+    assert sum(v for k, v in on.items() if k.endswith(", bsum>")) >= 3 and not any(k.endswith(", bsum>") for k in off)
+    assert "pass_a_kernel<UP>" not in on and off["pass_a_kernel<UP>"] == n          # middle + decoders 0 .. n-2
+    # (the first layer keeps its pass - its g feeds the fp32 weight gradient - and so does an encoder layer whose decimating consumer runs
+    #  below 256 samples)
+    assert 1 <= on.get("pass_a_kernel<ENC>", 0) < off["pass_a_kernel<ENC>"] == n
+    for k, g in got["256"][1].items():
+        r = got["0"][1][k]
+        assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1e-12), k
+
+
 def test_fused_adam_matches_torch(emu_engine):
     """the fused Adam launch against torch.optim.Adam (train.py:31-35), three steps."""
     optim_mod = importlib.import_module(PKG_NAME + ".optim")

@@ -158,3 +158,41 @@ def test_fused_loaders_on_ragged_and_padded_shapes(pkg, dev, B, T):
     off = {"WUNET_H3U": "0,0", "WUNET_NO_EVOP": "1"}
     _, _, out0 = _run(_engine(off), off, pkg, dev, noisy, False)
     assert (out - out0).abs().max().item() < 2e-6
+
+
+def test_bn_backward_sums_in_the_data_gradient_epilogue(pkg, dev):
+    """conv_h3d_kernel<.., BSUM> on the hardware (off by default - profiles/r6_bsum_ab.txt - so the planner switch WUNET_BSUM is set here): a
+    training step at batch 16 x 16384 with the BatchNorm-backward sums taken in the data gradients' epilogues from 1024 samples up equals the
+    same step with pass_a_kernel to the rounding of another summation order (1e-5 of each gradient tensor's maximum), the kernels really run
+    (profile names), and pass A is gone for those layers (unet_basic.py:12-13,25-26,86,93-95 backwards)."""
+    B, T = 16, 16384
+    noisy, clean = plan.golden_batch(B, T, 9)
+    sd = plan.golden_state(N, CI, 0)
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    res = {}
+    for bs in ("1024", "0"):
+        env = {"WUNET_BSUM": bs}
+        with _planned_under(env):
+            eng = eng_mod.Engine()
+            m = pkg.Model(n_layers=N, channels_interval=CI)
+            m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()})
+            m.to(dev).train()
+            crit = pkg.smooth_l1_loss()
+            m._engine_override = crit._engine_override = eng
+            eng.lib.wunet_profile_enable(1)
+            try:
+                out = m(torch.from_numpy(noisy).to(dev))
+                crit(torch.from_numpy(clean).to(dev), out).backward()
+                torch.cuda.synchronize()
+                buf = ctypes.create_string_buffer(1 << 16)
+                eng.lib.wunet_profile_collect(buf, len(buf))
+            finally:
+                eng.lib.wunet_profile_enable(0)
+            names = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().strip().splitlines()}
+            res[bs] = (names, {k: p.grad.clone() for k, p in m.named_parameters()})
+    on, off = res["1024"][0], res["0"][0]
+    assert sum(v for k, v in on.items() if k.endswith(", bsum>")) >= 6 and not any(k.endswith(", bsum>") for k in off), sorted(on)
+    assert on.get("pass_a_kernel<UP>", 0) < off["pass_a_kernel<UP>"] and on.get("pass_a_kernel<ENC>", 0) < off["pass_a_kernel<ENC>"]
+    for k, g in res["1024"][1].items():
+        r = res["0"][1][k]
+        assert (g - r).abs().max().item() <= 1e-5 * max(r.abs().max().item(), 1e-12) + 1e-9, k

@@ -24,8 +24,21 @@
         return 0;                                                                                          \
     }
 
-int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool evop)
+// BSUM: the training data gradient that also takes the producers' BatchNorm-backward sums (whole-row tiles, two planes): 5 taps = a decoder
+// layer (rows through the upsample + skip rows), 15 taps = an encoder-side layer (decimated rows)
+#define WUNET_XCASE_BSUM(T, M, K)                                                                          \
+    if (bsum == K && taps == T && mrep == M && nseg == 1 && !bf && !evop) {                                \
+        if (!WUNET_H3D_HAS_TAIL(M, 1) && a.NFS != a.NS) return -3;                                         \
+        if (WUNET_ALLOW_BIG_LDS((conv_h3d_kernel<T, M, 1, false, false, K>), smem) != 0) return -2;        \
+        WUNET_LAUNCH((conv_h3d_kernel<T, M, 1, false, false, K>), grid, dim3(WUNET_THREADS), smem, st, a); \
+        return 0;                                                                                          \
+    }
+
+int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool evop, int bsum)
 {
+    WUNET_XCASE_BSUM(5, 2, 1) WUNET_XCASE_BSUM(5, 3, 1) WUNET_XCASE_BSUM(5, 4, 1)
+    WUNET_XCASE_BSUM(15, 2, 2) WUNET_XCASE_BSUM(15, 3, 2) WUNET_XCASE_BSUM(15, 4, 2)
+    if (bsum) return -5;
     WUNET_XCASE_EVOP(2) WUNET_XCASE_EVOP(3) WUNET_XCASE_EVOP(4)
     if (evop) return -4;
     WUNET_XCASE(15, 2, 1) WUNET_XCASE(15, 3, 1) WUNET_XCASE(15, 4, 1)

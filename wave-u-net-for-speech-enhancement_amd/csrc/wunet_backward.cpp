@@ -70,6 +70,10 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
 
     for (int i = layer_end - 1; i >= layer_begin; --i) {
         const LayerPlan& l = c->ly[i];
+        // ---- a layer whose BatchNorm-backward sums came out of its consumers' data-gradient epilogues (conv_h3d_kernel<.., BSUM>, planned by
+        // layout_workspace): no pass A; finalize from the per-tile rows; g_z formed by gz_split_h3_kernel from the data gradients themselves
+        static const bool no_enc_gz_ = getenv("WUNET_NO_ENC_GZ") != nullptr;
+        const bool bsum = l.bsum && !(i < n && no_enc_gz_);
         // ---- pass A: assemble dL/d(BN output), LeakyReLU', BN-backward partial sums
         PassAArgs p{};
         p.z = ws + l.z; p.a = ws + l.a; p.s = ws + l.s; p.mean = ws + l.mean; p.rstd = ws + l.rstd;
@@ -96,12 +100,13 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         // mode) from them instead of written here and read back (WUNET_NO_ENC_GZ=1: A/B switch)
         static const bool no_enc_gz = getenv("WUNET_NO_ENC_GZ") != nullptr;
         const bool enc_in_gz = i > 0 && i < n && l.h3d && !fuse && !tiny && !dx_stays_split(c, i + 1) && !no_enc_gz;
-        {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
+        if (!bsum) {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
             const double pe = (double)c->B * l.cout * l.L;
             const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : "pass_a_kernel<ENC>";
             prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : i >= n ? 16.0 : (enc_in_gz ? 10.0 : 14.0)) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
         }
-        if (i == NL - 1) {
+        if (bsum) {
+        } else if (i == NL - 1) {
             if (head_in_gz) p.gpre = nullptr;
             p.g0 = ws + c->gh_off; p.g1 = params[4 * NL]; p.hpart = ws + c->hpart2_off;
             WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);      // (the last layer has T >= 4 samples)
@@ -139,8 +144,23 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
             // (short levels on the split kernels: the finalize runs in the prologue of gz_split_h3_kernel's blocks instead -
             //  WUNET_NO_BWDFIN_FUSE=1: A/B switch)
-            const bool fin_in_gz = i > 0 && l.h3d && l.a_split * l.cout <= WUNET_GZ_FIN_LOADS && l.cout <= WUNET_GZ_FIN_C;
-            if (!fin_in_gz) {
+            const bool fin_in_gz = !bsum && i > 0 && l.h3d && l.a_split * l.cout <= WUNET_GZ_FIN_LOADS && l.cout <= WUNET_GZ_FIN_C;
+            if (bsum) {
+                BnBwdTilesArgs t{};
+                if (i >= n) {            // one set: rows 0 .. c0 - 1 of the next decoder layer's data gradient
+                    const LayerPlan& q = c->ly[i + 1];
+                    t.part0 = ws + q.bsp; t.tiles0 = (int)(((size_t)c->B * q.L + 255) / 256);
+                } else {                 // the skip rows of decoder layer 2n - i, then the decimated rows of layer i + 1
+                    const LayerPlan& dq = c->ly[2 * n - i];
+                    const LayerPlan& eq = c->ly[i + 1];
+                    t.tiles0 = (int)(((size_t)c->B * dq.L + 255) / 256); t.part0 = ws + dq.bsp + (size_t)dq.c0 * t.tiles0 * 4;
+                    t.tiles1 = (int)(((size_t)c->B * eq.L + 255) / 256); t.part1 = ws + eq.bsp;
+                }
+                t.gamma = b.gamma; t.mean = b.mean; t.rstd = b.rstd; t.dgamma = b.dgamma; t.dbeta = b.dbeta; t.dbias = b.dbias;
+                t.k1 = b.k1; t.k2 = b.k2; t.k3 = b.k3; t.bound = b.bound; t.C = l.cout; t.count = b.count;
+                WUNET_LAUNCH(bn_finalize_bwd_tiles_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, t);
+                WUNET_CHECK_LAUNCH();
+            } else if (!fin_in_gz) {
                 WUNET_LAUNCH(bn_finalize_bwd_kernel, dim3(l.cout), dim3(WUNET_THREADS), 0, st, b);
                 WUNET_CHECK_LAUNCH();
             }
@@ -155,9 +175,14 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     const size_t nt = (size_t)c->B * c8 * (l.L / 4);
                     size_t hb = (nt + WUNET_THREADS - 1) / WUNET_THREADS;
                     if (hb > 8192) hb = 8192;
-                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * ((head_in_gz ? 4.0 : enc_in_gz ? 10.0 : 8.0) + (c->bf ? 2.0 : 4.0)));
+                    const bool up_in_gz = bsum && i >= n;
+                    prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * ((head_in_gz ? 4.0 : enc_in_gz ? 10.0 : up_in_gz ? 12.0 : 8.0) + (c->bf ? 2.0 : 4.0)));
                     GzHeadArgs hd{};
                     if (head_in_gz) { hd.gh = ws + c->gh_off; hd.wh = params[4 * NL]; hd.a = ws + l.a; hd.s = ws + l.s; }
+                    if (up_in_gz) {
+                        const LayerPlan& q = c->ly[i + 1];
+                        hd.gu = ws + q.dx; hd.Cg0 = q.cin; hd.up_scale = (float)(l.Lt - 1) / (float)(2 * l.Lt - 1); hd.a = ws + l.a; hd.s = ws + l.s;
+                    }
                     if (enc_in_gz) {
                         const LayerPlan& dc = c->ly[2 * n - i];
                         hd.gd = ws + dc.dx; hd.Cg0 = dc.cin; hd.coff = dc.c0; hd.ge = ws + c->ly[i + 1].dx; hd.a = ws + l.a; hd.s = ws + l.s;
@@ -259,12 +284,24 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             wunet_half* gh = reinterpret_cast<wunet_half*>(ws + l.gzh);
             wunet_half* gl = reinterpret_cast<wunet_half*>(ws + l.gzl);
             const bool split = l.d.ksplit > 1;
+            // (BSUM: the epilogue also takes the BatchNorm-backward sums of the layers that produced this layer's input rows)
+            ConvH3Bsum bs{};
+            if (l.bs_kind && !split) {
+                const LayerPlan& pa = c->ly[l.src0];
+                bs.kind = l.bs_kind; bs.c0 = l.c0; bs.up_scale = (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1); bs.part = ws + l.bsp;
+                const bool on_a = pa.bsum && !(l.src0 < n && no_enc_gz_);
+                bs.z[0] = on_a ? ws + pa.z : nullptr; bs.cst[0] = ws + pa.cst; bs.C[0] = pa.cout;
+                if (l.bs_kind == 1) {
+                    const LayerPlan& pb = c->ly[l.src1];
+                    bs.z[1] = (pb.bsum && !no_enc_gz_) ? ws + pb.z : nullptr; bs.cst[1] = ws + pb.cst; bs.C[1] = pb.cout;
+                }
+            }
             int rc = launch_conv_h3(l.taps, l.h3d_mrep, l.h3d_mtp, l.h3d_sps, gh, gl,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_hi) + l.h3d_wpk,
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
                                     ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2,
                                     split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st, ws + l.gzp, nullptr, nullptr,
-                                    nullptr, c->bf, l.h3d_ntt);
+                                    nullptr, c->bf, l.h3d_ntt, nullptr, (bs.z[0] || bs.z[1]) ? &bs : nullptr);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
             if (split && !dx_stays_split(c, i)) {

@@ -35,11 +35,25 @@ __device__ __forceinline__ float wunet_row16_sum(float v)
 #undef WUNET_DPP_ADD
     return v;
 }
+// maximum of v (>= 0) over the 16 lanes of a row, in every lane, by the same DPP moves
+__device__ __forceinline__ float wunet_row16_max(float v)
+{
+#define WUNET_DPP_MAX(CTRL_) v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL_, 0xf, 0xf, false)))
+    WUNET_DPP_MAX(0xB1);
+    WUNET_DPP_MAX(0x4E);
+    WUNET_DPP_MAX(0x141);
+    WUNET_DPP_MAX(0x140);
+#undef WUNET_DPP_MAX
+    return v;
+}
 // 16-byte staging registers are the NATIVE vector type: arrays of HIP's float4 struct carried across loop
 // iterations were demoted to scratch memory by hipcc (global_load -> vmcnt(0) -> scratch_store), which
 // silently serialised the software pipeline.
 __device__ __forceinline__ wunet_f4 wunet_ld4(const float* p) { return *reinterpret_cast<const wunet_f4*>(p); }
 __device__ __forceinline__ void wunet_st4(float* p, wunet_f4 v) { *reinterpret_cast<wunet_f4*>(p) = v; }
+// 16 bytes from a 4-byte aligned address (global_load_dwordx4 needs dword alignment only; the type tells the compiler not to assume more)
+typedef float wunet_f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ wunet_f4 wunet_ld4u(const float* p) { const wunet_f4u t = *reinterpret_cast<const wunet_f4u*>(p); return wunet_f4{t[0], t[1], t[2], t[3]}; }
 __device__ __forceinline__ wunet_f4 wunet_sel4(bool ok, wunet_f4 v) { return ok ? v : wunet_f4{0.f, 0.f, 0.f, 0.f}; }
 
 // ---- fp16 split ("h3") arithmetic: x = hi + lo with hi, lo fp16 (22 significant bits together); a product is

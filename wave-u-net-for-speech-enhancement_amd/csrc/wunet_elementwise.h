@@ -102,6 +102,7 @@ struct BnFwdArgs {
     float* s;             // out: shift  beta - mean*a
     float* mean;          // out (training): batch mean of z
     float* rstd;          // out (training)
+    float* cst;           // out (training) or nullptr: the same four as ONE 16-byte row per channel {a, s, mean, rstd} (conv_h3d_kernel<.., BSUM> loads a row's constants with one instruction)
     int C;
     double count;         // B*L
     int training;
@@ -120,6 +121,7 @@ __device__ __forceinline__ void bn_finalize_core(const BnFwdArgs& A, int c, doub
     A.s[c] = A.beta[c] - (float)mean * a;
     A.mean[c] = (float)mean;
     A.rstd[c] = rstd;
+    if (A.cst) { A.cst[4 * c] = a; A.cst[4 * c + 1] = A.s[c]; A.cst[4 * c + 2] = (float)mean; A.cst[4 * c + 3] = rstd; }
     const double unbiased = A.count > 1.0 ? var * A.count / (A.count - 1.0) : var;
     A.running_mean[c] = (float)(0.9 * (double)A.running_mean[c] + 0.1 * mean);
     A.running_var[c] = (float)(0.9 * (double)A.running_var[c] + 0.1 * unbiased);
@@ -398,6 +400,62 @@ static __global__ __launch_bounds__(WUNET_THREADS) void rows_sum_kernel(const fl
 //   A_ENC  : g_y[b,c,l] = dXdec[b, coff+c, l] + (l even ? dXenc[b,c,l/2] : 0)   (skip + decimation^T)
 // grid = (C, nsplit); part[split][C][2].
 enum { A_HEAD = 0, A_UP = 1, A_ENC = 2 };
+
+// Transposed x2 upsample of ONE row, four inputs at a time, for callers that walk several channels at the same positions (gz_split_h3_kernel's
+// UP mode: 8 channels per thread): the coordinates of outputs 2l - 1 .. 2l + 8 once (wunet_upT_coords), then per row the ten data-gradient
+// values and sixteen multiply-adds (wunet_upT_row) - pass_a_kernel<A_UP>'s arithmetic in pass_a_kernel's order: input i receives, in ascending
+// j, l1(2i-1) d[2i-1] + l1(2i) d[2i] + l0(2i+1) d[2i+1] + l0(2i+2) d[2i+2].  `fast`: interior positions whose outputs read the regular
+// source pairs ((j-1) >> 1, +1) (checked against ATen's fp32 coordinates); the row ends take the general form.
+struct WunetUpT { float c0[10], c1[10]; bool fast; };
+__device__ __forceinline__ void wunet_upT_coords(int l, int Lt, float up_scale, WunetUpT& U)
+{
+    const int j0 = 2 * l - 4;
+    U.fast = l >= 4 && l + 8 <= Lt;
+    if (U.fast) {
+#pragma unroll
+        for (int k = 3; k <= 12; ++k) {
+            int i0, i1;
+            wunet_up_coord(j0 + k, Lt, up_scale, i0, i1, U.c0[k - 3], U.c1[k - 3]);
+            U.fast = U.fast && i0 == ((j0 + k - 1) >> 1) && i1 == i0 + 1;
+        }
+    }
+}
+// row: the data gradient of one (item, channel) at 2L samples (row stride Lo = 2L, Lot = 2 Lt of them exist); g: inputs l .. l + 3
+__device__ __forceinline__ void wunet_upT_row(const float* row, int l, int Lo, int Lot, int Lt, float up_scale, const WunetUpT& U, float (&g)[4])
+{
+    const int j0 = 2 * l - 4;
+    g[0] = g[1] = g[2] = g[3] = 0.0f;
+    if (U.fast) {
+        const float dm = row[j0 + 3];
+        const wunet_f4 da = wunet_ld4(row + j0 + 4), db = wunet_ld4(row + j0 + 8);
+        const float dl = row[j0 + 12];
+        const float d[10] = {dm, da[0], da[1], da[2], da[3], db[0], db[1], db[2], db[3], dl};      // outputs 2l - 1 .. 2l + 8
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            g[m] += U.c1[2 * m] * d[2 * m];
+            g[m] += U.c1[2 * m + 1] * d[2 * m + 1];
+            g[m] += U.c0[2 * m + 2] * d[2 * m + 2];
+            g[m] += U.c0[2 * m + 3] * d[2 * m + 3];
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 2; k <= 12; ++k) {                   // j = 2l-2 .. 2l+8, ascending like ATen's backward loop
+        const int j = j0 + k;
+        if (j >= 0 && j < Lot) {
+            const float dv = row[j];
+            int i0, i1; float l0, l1;
+            wunet_up_coord(j, Lt, up_scale, i0, i1, l0, l1);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float w = (i0 == l + m ? l0 : 0.0f) + (i1 == l + m ? l1 : 0.0f);
+                g[m] += w * dv;
+            }
+        }
+    }
+    (void)Lo;
+}
+
 struct PassAArgs {
     const float* z;      // [B][C][L]
     const float* a;      // scale/shift of this layer (sign of the pre-activation)
@@ -637,6 +695,65 @@ static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(B
             const double a = (double)A.gamma[c] * (double)A.rstd[c];
             A.bound[c] = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)A.rstd[c]) * (double)mz + fabs(a * m1));
         }
+    }
+}
+
+// The same finalize for a layer whose sums were taken by its consumers' data-gradient epilogues (conv_h3d_kernel<.., BSUM>): up to two sets
+// of per-tile rows [channel][tiles][4] = {sum g, sum g xhat, bound of max |g|, max |z - mean|} - the skip consumer's and the decimating
+// consumer's for an encoder layer, one set for a layer that feeds an upsample.  Sums: tiles in order, set 0 then set 1, in double;
+// max |g| <= the sum of the two sets' bounds (g is the sum of the two consumers' gradients).
+struct BnBwdTilesArgs {
+    const float* part0; int tiles0;      // rows of THIS layer's channel c start at part0 + c * tiles0 * 4 (the caller applied the row offset)
+    const float* part1; int tiles1;      // nullptr: one set
+    const float* gamma; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; float* bound;
+    int C; double count;
+};
+static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_tiles_kernel(BnBwdTilesArgs A)
+{
+    __shared__ double red[2 * WUNET_THREADS];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    float mg0 = 0.0f, mg1 = 0.0f, mz = 0.0f;
+    {
+        const float* p = A.part0 + (size_t)c * A.tiles0 * 4;
+        int r = tid;
+        for (; r + 3 * WUNET_THREADS < A.tiles0; r += 4 * WUNET_THREADS) {      // (four loads in flight, same order of additions)
+            const wunet_f4 v0 = wunet_ld4(p + 4 * (size_t)r), v1 = wunet_ld4(p + 4 * (size_t)(r + WUNET_THREADS));
+            const wunet_f4 v2 = wunet_ld4(p + 4 * (size_t)(r + 2 * WUNET_THREADS)), v3 = wunet_ld4(p + 4 * (size_t)(r + 3 * WUNET_THREADS));
+            s1 += (double)v0[0]; s2 += (double)v0[1]; s1 += (double)v1[0]; s2 += (double)v1[1];
+            s1 += (double)v2[0]; s2 += (double)v2[1]; s1 += (double)v3[0]; s2 += (double)v3[1];
+            mg0 = fmaxf(fmaxf(mg0, v0[2]), fmaxf(fmaxf(v1[2], v2[2]), v3[2]));
+            mz = fmaxf(fmaxf(mz, v0[3]), fmaxf(fmaxf(v1[3], v2[3]), v3[3]));
+        }
+        for (; r < A.tiles0; r += WUNET_THREADS) {
+            const wunet_f4 v = wunet_ld4(p + 4 * (size_t)r);
+            s1 += (double)v[0]; s2 += (double)v[1]; mg0 = fmaxf(mg0, v[2]); mz = fmaxf(mz, v[3]);
+        }
+    }
+    if (A.part1) {
+        const float* p = A.part1 + (size_t)c * A.tiles1 * 4;
+        for (int r = tid; r < A.tiles1; r += WUNET_THREADS) {
+            const wunet_f4 v = wunet_ld4(p + 4 * (size_t)r);
+            s1 += (double)v[0]; s2 += (double)v[1]; mg1 = fmaxf(mg1, v[2]); mz = fmaxf(mz, v[3]);
+        }
+    }
+    block_sum2(s1, s2, red);
+    __syncthreads();
+    block_max2(mg0, mg1, red);
+    __syncthreads();
+    float dummy = 0.0f;
+    block_max2(mz, dummy, red);
+    if (tid == 0) {
+        A.dgamma[c] = (float)s2;
+        A.dbeta[c] = (float)s1;
+        A.dbias[c] = 0.0f;
+        const double m1 = s1 / A.count, m2 = s2 / A.count;
+        const double a = (double)A.gamma[c] * (double)A.rstd[c];
+        A.k1[c] = (float)a;
+        A.k2[c] = (float)(-a * m2 * (double)A.rstd[c]);
+        A.k3[c] = (float)(a * m2 * (double)A.rstd[c] * (double)A.mean[c] - a * m1);
+        A.bound[c] = (float)(fabs(a) * ((double)mg0 + (double)mg1) + fabs(a * m2 * (double)A.rstd[c]) * (double)mz + fabs(a * m1));
     }
 }
 

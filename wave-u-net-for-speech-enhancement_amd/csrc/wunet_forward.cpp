@@ -264,6 +264,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         b.gamma = params[4 * i + 2]; b.beta = params[4 * i + 3];
         b.running_mean = running[2 * i]; b.running_var = running[2 * i + 1]; b.nbt = nbt[i];
         b.a = ws + l.a; b.s = ws + l.s; b.mean = ws + l.mean; b.rstd = ws + l.rstd;
+        b.cst = (training && l.bsum) ? ws + l.cst : nullptr;      // (read by the consumers' data-gradient epilogues, conv_h3d_kernel<.., BSUM>)
         b.C = l.cout; b.count = (double)c->B * l.Lt; b.training = training ? 1 : 0;
         // eval mode, a layer whose activation feeds split operands: its consumers' operand scale comes from the measured maximum
         // of |a z + s| (no batch statistics bound it).  The large producers (conv_first_kernel, un-split conv_h3_kernel) take it

@@ -63,6 +63,26 @@ struct ConvH3Args {
     wunet_half* op_h; wunet_half* op_l;
     const float* op_wl1; const float* op_xmax; float* op_xsc;
     int op_C8;
+    // BSUM (training backward, a data gradient on un-split whole-row tiles; conv_h3d_kernel<.., BSUM = 1 | 2>): the rows this launch
+    // writes are dL/d(conv input) = the gradients w.r.t. the ACTIVATIONS of the layers that produced that input.  BatchNorm backward
+    // of a producer needs sum g and sum g * xhat over its positions with g = dL/d(activation) * LeakyReLU'(a z + s) - linear in
+    // the data gradient, so the epilogue takes them from the accumulators while they are still in registers (it reads the producer's raw z
+    // tile, 4 bytes per value) and pass_a_kernel - a whole pass over z and the data gradients - disappears for that producer:
+    //   BSUM = 1, a decoder layer (model/unet_basic.py:93-95 backwards): rows < bs_c0 came through the x2 upsample of producer A
+    //            (z at L/2): sum_q mask_q sum_p U[p,q] dx[p] = sum_p dx[p] (U mask)[p], i.e. the sums are taken against the UPSAMPLED
+    //            mask and mask * xhat (ATen's fp32 coordinates, pairs ((p-1) >> 1, +1): wunet_plan.cpp up_pairs_regular) - the
+    //            transposed upsample itself is left to gz_split_h3_kernel; rows >= bs_c0 are the skip of producer B (z at L, same
+    //            position);
+    //   BSUM = 2, an encoder-side layer (:86 backwards): every row is the decimated activation of producer A (z at 2L, even samples).
+    // Per tile and row {sum g, sum g xhat, bound of max |g|, max |z - mean|} go to bs_part [rows][ntiles][4] (fixed order: the four
+    // waves' parts are added in wave order, bn_finalize_bwd_tiles_kernel adds the tiles in order).  A producer whose pointers are null
+    // is skipped (it keeps pass_a_kernel).
+    const float* bs_z[2];                         // raw conv outputs of producers A, B
+    const float* bs_cst[2];                       // their BatchNorm constants [C][4] = {a, s, mean, rstd} (bn_finalize_core writes the table)
+    int bs_C[2];                                  // channel counts of the producers (row strides of their z)
+    int bs_c0;                                    // first row of producer B
+    float bs_up_scale;                            // BSUM = 1: (float)(L/2 - 1) / (float)(L - 1)
+    float* bs_part;
 };
 
 // ---------------------------------------------------------------------------- weight gradient

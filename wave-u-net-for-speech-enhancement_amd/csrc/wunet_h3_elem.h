@@ -287,9 +287,13 @@ static __global__ __launch_bounds__(WUNET_THREADS) void wgrad_h3_reduce_kernel(W
 // ENC (an encoder layer whose data gradients are whole tensors): its g = (dXdec[b, coff+c, l] + (l even ? dXenc[b, c, l/2] : 0)) * LeakyReLU'
 // (pass_a_kernel<A_ENC>'s arithmetic, bit for bit) is recomputed here from the two data gradients (6 bytes per value read instead of
 // the 4 of g) so that pass A does not WRITE g (4 bytes per value; a written byte costs 1.4 x a read one on this part).
+// UP (a layer that feeds an upsample and whose BatchNorm-backward sums came out of the consumer's data-gradient epilogue, conv_h3d_kernel<.., BSUM>:
+// no pass A ran, no g exists): g = upsample^T(dX of the next decoder layer) * LeakyReLU' is formed here from dX [B][Cg0][2L] (8 bytes per value
+// read instead of the 4 of a stored g; wunet_upT_row - pass_a_kernel<A_UP>'s arithmetic).
 struct GzHeadArgs {
-    const float* gh; const float* wh; const float* a; const float* s;      // HEAD (gh != nullptr); a, s also ENC
+    const float* gh; const float* wh; const float* a; const float* s;      // HEAD (gh != nullptr); a, s also ENC and UP
     const float* gd; const float* ge; int Cg0, coff;                        // ENC (gd != nullptr): dXdec [B][Cg0][L], dXenc [B][C][L/2]
+    const float* gu; float up_scale;                                        // UP (gu != nullptr): dX [B][Cg0][2L]; (float)(Lt-1)/(2Lt-1)
 };
 #define WUNET_GZ_FIN_LOADS 1536   // (sweep 1152 / 2048 / 3100 / all: 5.41 / 5.42 / 5.46 / 5.50 ms per step - beyond the 512-sample level the prologue costs more than the launch)
 #define WUNET_GZ_FIN_C 512
@@ -372,6 +376,8 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
             wunet_f4 v[8];
             wunet_f4 gh4 = wunet_f4{0.f, 0.f, 0.f, 0.f};
             if (H.gh) gh4 = wunet_ld4(H.gh + (size_t)b * L + 4 * l4);
+            WunetUpT U;
+            if (H.gu) wunet_upT_coords(4 * l4, Lt, H.up_scale, U);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = c8 * 8 + e;
@@ -396,6 +402,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (!(ha * zv[j] + hs > 0.0f)) gv[j] *= WUNET_SLOPE;
+                } else if (H.gu) {
+                    float gg[4];
+                    wunet_upT_row(H.gu + ((size_t)b * H.Cg0 + cc) * (size_t)(2 * L), 4 * l4, 2 * L, 2 * Lt, Lt, H.up_scale, U, gg);
+                    const float ha = H.a[cc], hs = H.s[cc];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) gv[j] = (ha * zv[j] + hs > 0.0f) ? gg[j] : gg[j] * WUNET_SLOPE;
                 } else gv = wunet_ld4(g + o);
                 const float a = FIN ? ks[cc] : k1[cc], bb = FIN ? ks[WUNET_GZ_FIN_C + cc] : k2[cc], d = FIN ? ks[2 * WUNET_GZ_FIN_C + cc] : k3[cc];
 #pragma unroll

@@ -29,9 +29,10 @@
 
 // (no tail stages in the two shapes at the register limit: they would spill)
 #define WUNET_H3D_HAS_TAIL(M_REP_, NSEG_) ((M_REP_) < 4 && (NSEG_) < 16)
-template <int TAPS, int M_REP, int NSEG, bool BF = false, bool EVOP = false>
+template <int TAPS, int M_REP, int NSEG, bool BF = false, bool EVOP = false, int BSUM = 0>
 __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A)
 {
+    static_assert(BSUM == 0 || (NSEG == 1 && !BF && !EVOP), "BSUM: a training data gradient on whole-row tiles");
     constexpr int PAD = TAPS / 2;
     constexpr int TG = 5;                         // taps per stage
     constexpr int NTG = TAPS / TG;
@@ -46,11 +47,13 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
     WUNET_DYN_SMEM(smem);
     wunet_half* xs = reinterpret_cast<wunet_half*>(smem);             // [hi|lo][4][COLS, de-interleaved][8]
     wunet_half* ws = xs + XP * 8;                                      // [hi|lo][M_REP][TG][4][16][8]
-    float* red = reinterpret_cast<float*>(ws + WP * 8);                // [4 waves][M_REP * 16][2] statistics hand-over, + 4 maxima
+    float* red = reinterpret_cast<float*>(ws + WP * 8);                // [4 waves][M_REP * 16][2] statistics hand-over (BSUM: [4] per row), + 4 maxima
     // un-segmented tiles (the levels of 256 samples and more): [bias | eval a | eval s][ER], the epilogue's per-row constants, once per block
-    // instead of one global round trip per work item (the eval parts only where A.epi_eval says they fit)
-    constexpr bool EPI_LDS = NSEG == 1;
-    float* const epi = red + WUNET_WAVES * M_REP * 32 + 4;
+    // instead of one global round trip per work item (the eval parts only where A.epi_eval says they fit).  (BSUM: a data gradient has
+    // no bias - no table; its LDS goes into the wider hand-over rows.)
+    constexpr bool EPI_LDS = NSEG == 1 && BSUM == 0;
+    constexpr int RW = BSUM ? 64 : 32;                                 // hand-over floats per 16 rows
+    float* const epi = red + WUNET_WAVES * M_REP * RW + 4;
     const int ER = A.mblocks * M_REP * 16;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
@@ -391,6 +394,126 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             }                                                                                                     \
         }                                                                                                         \
     }
+        if (BSUM) {
+            // ---- data gradient + the producers' BatchNorm-backward sums (ConvH3Args::bs_*).  Two phases: (A) the sums, from the accumulators
+            // and the producers' z rows - loads only, a ring of D rows in flight (hipcc counts loads and stores in ONE counter and waits
+            // for vmcnt(0) as soon as both kinds are pending: a load issued behind a store would wait for that store to reach the L2);
+            // (B) the stores of the data gradient itself, as in the plain epilogue, drained under the next item's K loop.
+            // (everything below derives from values made opaque HERE: what does not depend on the work item would otherwise be hoisted out of the
+            //  loop over the items and live through the K loop, whose registers are spoken for)
+            int qe = q, pe = ll0;
+            wunet_opaque(qe);
+            wunet_opaque(pe);
+            const int p0 = l0 + pe;                 // first of the lane's four positions in its row
+            float uw0[4] = {1.f, 1.f, 1.f, 1.f}, uw1[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BSUM == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { int i0_, i1_; wunet_up_coord(p0 + j, L >> 1, A.bs_up_scale, i0_, i1_, uw0[j], uw1[j]); }
+            }
+            constexpr int NR = 4 * M_REP;                                         // rows of this lane: (m-tile, r)
+#ifndef WUNET_BS_D
+#define WUNET_BS_D 4
+#endif
+            constexpr int D = WUNET_BS_D < NR ? WUNET_BS_D : NR;                  // rows in flight (8 / 12 registers each)
+            wunet_f4 zq[D], zr[D], cq[D];
+            bool bs_on[D];
+            int bs_pk[D];
+#define WUNET_H3D_BS_LOAD(RR_)                                                                                    \
+    {                                                                                                             \
+        const int sl_ = (RR_) % D, mt_ = (RR_) >> 2, r_ = (RR_) & 3;                                              \
+        const int rb_ = (mt0 + mt_) * 16 + qe * 4;                                                                \
+        const int pk_ = (BSUM == 1 && rb_ >= A.bs_c0) ? 1 : 0;                                                    \
+        const float* const zb_ = pk_ ? A.bs_z[1] : A.bs_z[0];                                                     \
+        bs_pk[sl_] = pk_;                                                                                         \
+        bs_on[sl_] = rb_ < A.Cout && bo < A.B && zb_ != nullptr;                                                  \
+        if (bs_on[sl_]) {                                                                                         \
+            const int ch_ = rb_ - (pk_ ? A.bs_c0 : 0) + r_;                                                       \
+            const int ls_ = BSUM == 2 ? 2 * L : (pk_ ? L : (L >> 1));          /* the producer's row length */    \
+            const float* const zp_ = zb_ + ((size_t)bo * (pk_ ? A.bs_C[1] : A.bs_C[0]) + ch_) * ls_               \
+                                     + (BSUM == 2 ? 2 * p0 : pk_ ? p0 : (p0 >> 1) - 1);                           \
+            cq[sl_] = wunet_ld4((pk_ ? A.bs_cst[1] : A.bs_cst[0]) + 4 * ch_);                                     \
+            if (BSUM == 2) { zq[sl_] = wunet_ld4(zp_); zr[sl_] = wunet_ld4(zp_ + 4); }                            \
+            else if (pk_) zq[sl_] = wunet_ld4(zp_);                                                               \
+            else zq[sl_] = wunet_ld4u(zp_);                           /* sources (p0 >> 1) - 1 .. + 2 */          \
+        }                                                                                                         \
+    }
+#pragma unroll
+            for (int rr = 0; rr < D; ++rr) WUNET_H3D_BS_LOAD(rr)
+#pragma unroll
+            for (int rr = 0; rr < NR; ++rr) {
+                const int sl = rr % D, mt = rr >> 2, r = rr & 3;
+                float s1 = 0.0f, s2 = 0.0f, mg = 0.0f, mz = 0.0f;
+                if (bs_on[sl]) {
+                    wunet_f4 o;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) o[nt] = acc[mt][nt][r] * inv12;
+                    const wunet_f4 k = cq[sl];            // a, s, mean, rstd of the row's producer channel
+                    float zs[4];
+                    if (BSUM == 2) { zs[0] = zq[sl][0]; zs[1] = zq[sl][2]; zs[2] = zr[sl][0]; zs[3] = zr[sl][2]; }
+                    else { zs[0] = zq[sl][0]; zs[1] = zq[sl][1]; zs[2] = zq[sl][2]; zs[3] = zq[sl][3]; }
+                    if (BSUM == 1 && !bs_pk[sl]) {
+                        // through the x2 upsample: the lane's outputs p0 .. p0 + 3 read the source pairs (0, 1), (1, 2), (1, 2), (2, 3)
+                        // of zs = sources (p0 >> 1) - 1 .. + 2; the row's first output reads source 0 with weight 1 (the clamped -1),
+                        // the last one has weight 0 on the sample behind the row (up_pairs_regular): selects, never arithmetic
+                        if (p0 == 0) zs[0] = zs[1];
+                        if (p0 + 4 >= L) zs[3] = zs[2];
+                        float m[4], e[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float d = zs[i] - k[2];
+                            m[i] = (k[0] * zs[i] + k[1] > 0.0f) ? 1.0f : WUNET_SLOPE;
+                            e[i] = m[i] * (d * k[3]);
+                            mz = fmaxf(mz, fabsf(d));
+                        }
+                        const float mm[4] = {uw0[0] * m[0] + uw1[0] * m[1], uw0[1] * m[1] + uw1[1] * m[2],
+                                             uw0[2] * m[1] + uw1[2] * m[2], uw0[3] * m[2] + uw1[3] * m[3]};
+                        const float me[4] = {uw0[0] * e[0] + uw1[0] * e[1], uw0[1] * e[1] + uw1[1] * e[2],
+                                             uw0[2] * e[1] + uw1[2] * e[2], uw0[3] * e[2] + uw1[3] * e[3]};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            s1 = fmaf(o[j], mm[j], s1);
+                            s2 = fmaf(o[j], me[j], s2);
+                            mg = fmaxf(mg, 2.0f * fabsf(o[j]));      // |g[i]| <= sum_p U[p, i] |dx[p]| <= 2 max |dx|
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float d = zs[j] - k[2];
+                            const float g = (k[0] * zs[j] + k[1] > 0.0f) ? o[j] : WUNET_SLOPE * o[j];
+                            s1 += g;
+                            s2 = fmaf(g, d * k[3], s2);
+                            mg = fmaxf(mg, fabsf(g));
+                            mz = fmaxf(mz, fabsf(d));
+                        }
+                    }
+                }
+                if (rr + D < NR) WUNET_H3D_BS_LOAD(rr + D)
+                s1 = wunet_row16_sum(s1);
+                s2 = wunet_row16_sum(s2);
+                mg = wunet_row16_max(mg);
+                mz = wunet_row16_max(mz);
+                if (i16 == 0) wunet_st4(red + ((wave * M_REP + mt) * 16 + qe * 4 + r) * 4, wunet_f4{s1, s2, mg, mz});
+                wunet_sched_fence();
+            }
+#undef WUNET_H3D_BS_LOAD
+            wunet_sched_fence();
+            // (B) the data gradient itself
+            if (full) { WUNET_H3D_ROWS(false, false, false) } else { WUNET_H3D_ROWS(false, true, false) }
+            // one row of sums per tile and GEMM row: the four waves' parts in wave order
+            wunet_wait_lds_barrier();
+            if (tid < M_REP * 16) {
+                const float* rp = red + tid * 4;
+                wunet_f4 t = wunet_f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w = 0; w < WUNET_WAVES; ++w) {
+                    const wunet_f4 v = wunet_ld4(rp + w * M_REP * 64);
+                    t[0] += v[0]; t[1] += v[1]; t[2] = fmaxf(t[2], v[2]); t[3] = fmaxf(t[3], v[3]);
+                }
+                const int row = mt0 * 16 + tid;
+                const float* const zb = (BSUM == 1 && row >= A.bs_c0) ? A.bs_z[1] : A.bs_z[0];
+                if (row < A.Cout && zb != nullptr) wunet_st4(A.bs_part + ((size_t)row * A.ntiles + tile) * 4, t);
+            }
+        } else
         if (A.xrows) { WUNET_H3D_ROWS(false, true, true) }          // eval mode: the maximum of the activation bound instead of statistics
         else if (want_stats) { if (full) { WUNET_H3D_ROWS(true, false, false) } else { WUNET_H3D_ROWS(true, true, false) } }
         else { if (full) { WUNET_H3D_ROWS(false, false, false) } else { WUNET_H3D_ROWS(false, true, false) } }

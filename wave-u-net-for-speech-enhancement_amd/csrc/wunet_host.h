@@ -90,6 +90,11 @@ struct LayerPlan {
     size_t xh, xl, xzp;           // split activated input (float offsets): hi plane, lo plane right behind it, then 16 zero bytes (DMA pad)
     size_t gzh, gzl, gzp;         // split scaled g_z (float offsets), likewise
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
+    // BatchNorm-backward sums out of the consumers' data-gradient epilogues (conv_h3d_kernel<.., BSUM>, ConvH3Args::bs_*)
+    size_t cst;                   // [cout][4] {a, s, mean, rstd}: the layer's BatchNorm constants as one 16-byte row per channel (training forward)
+    int bsum;                     // THIS layer's sums come from its consumers' epilogues: no pass_a_kernel, g_z from the data gradients
+    int bs_kind;                  // this layer's own data gradient takes sums for (some of) its producers: 1 decoder form, 2 encoder form
+    size_t bsp;                   // ... and writes them here: [cin][tiles][4]
 };
 
 // Tiling of conv_h3d_kernel for one GEMM (rows x B*L positions, K = kch channels x taps): accumulator rows per wave, padded
@@ -97,7 +102,7 @@ struct LayerPlan {
 // single-op entry points, so a geometry gets the same kernel instantiation either way.
 struct H3ConvPlan { int mrep, mtp, nch, sps, ksplit, ntiles, ntt; };
 H3ConvPlan plan_h3_conv(int B, int L, int rows, int kch, int taps, const char* order_env, int bf = 0);
-size_t h3d_smem(int nseg, int mrep, int bf, int mtp, int eval);          // dynamic LDS of a conv_h3d_kernel block
+size_t h3d_smem(int nseg, int mrep, int bf, int mtp, int eval, int bsum = 0);          // dynamic LDS of a conv_h3d_kernel block
 int h3d_blocks_per_cu(int nseg, int mrep, int bf);   // resident blocks per CU at that size
 int h3_stage_count(int kch, int taps, int ntt);
 void plan_h3_wgrad(LayerPlan& l, int B);
@@ -140,10 +145,13 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
                  int B, int C, int L, hipStream_t st, int bf = 0);
 // (op: eval mode, the conv also writes the next encoder layer's operand - ConvH3Args::op_*, conv_h3d_kernel<.., EVOP>)
 struct ConvH3OpOut { wunet_half* h; wunet_half* l; const float* wl1; const float* xmax; float* xsc; int C8; };
+// (bs: training backward, the data gradient also takes the BatchNorm-backward sums of the layers that produced its rows - ConvH3Args::bs_*,
+//  conv_h3d_kernel<.., BSUM = kind>; a producer with z == nullptr keeps pass_a_kernel)
+struct ConvH3Bsum { int kind; const float* z[2]; const float* cst[2]; int C[2]; int c0; float up_scale; float* part; };
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a = nullptr, const float* ev_s = nullptr,
-                   float* xrows = nullptr, int bf = 0, int ntt = 0, const ConvH3OpOut* op = nullptr);
+                   float* xrows = nullptr, int bf = 0, int ntt = 0, const ConvH3OpOut* op = nullptr, const ConvH3Bsum* bs = nullptr);
 int launch_conv_h3u(const ConvH3uArgs& a, int mrep, int mtiles_p, int kch, hipStream_t st);
 int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* xl, const wunet_half* gh, const wunet_half* gl,
                     const float* sc, const float* sc2, float* part, int B, hipStream_t st, int bf = 0);

@@ -37,6 +37,6 @@ struct ConvH3uArgs;
 struct WgradH3Args;
 struct WgradH3dArgs;
 int wunet_launch_wgrad_h3d(const WgradH3dArgs& a, int taps, int mrep, bool db, dim3 grid, size_t smem, hipStream_t st, bool bf, int tp);
-int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool evop = false);
+int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim3 grid, size_t smem, hipStream_t st, bool bf, bool evop = false, int bsum = 0);
 int wunet_launch_conv_h3u(const ConvH3uArgs& a, int mrep, dim3 grid, size_t smem, hipStream_t st);
 int wunet_launch_wgrad_h3(const WgradH3Args& a, int taps, int mrep, int nseg, int tp, dim3 grid, size_t smem, hipStream_t st, bool bf);

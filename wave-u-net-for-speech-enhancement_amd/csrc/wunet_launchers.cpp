@@ -111,7 +111,7 @@ int h3_grid_cap()
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a, const float* ev_s, float* xrows, int bf, int ntt,
-                   const ConvH3OpOut* op)
+                   const ConvH3OpOut* op, const ConvH3Bsum* bs)
 {
     // conv_h3d_kernel addresses its DMA pieces as SGPR base + unsigned 32-bit offset: lo plane / lo pack behind the hi one, the zero pad
     // behind both, everything within 4 GiB of the hi arrays
@@ -135,12 +135,23 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     a.ntiles = (int)((posn + 255) / 256); a.mblocks = mtiles_p / mrep;
     a.trace = g_h3_trace;
     if (op && (ksplit != 1 || nseg != 1 || !ev_a || !xrows)) return fail(WUNET_E_ARG, "conv_h3d EVOP needs an un-split whole-row eval launch");
+    if (bs) {
+        if (ksplit != 1 || nseg != 1 || bf || op || bias || stats || xrows || (rows & 3) || (bs->c0 & 3) || !bs->part || (bs->kind != 1 && bs->kind != 2) ||
+            (bs->kind == 1) != (taps == 5))
+            return fail(WUNET_E_ARG, "conv_h3d BSUM needs an un-split whole-row data gradient with rows in groups of four");
+        for (int k = 0; k < 2; ++k) { a.bs_z[k] = bs->z[k]; a.bs_cst[k] = bs->cst[k]; a.bs_C[k] = bs->C[k]; }
+        a.bs_c0 = bs->kind == 1 ? bs->c0 : rows; a.bs_up_scale = bs->up_scale; a.bs_part = bs->part;
+    }
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
-    snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
-    prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)) + (op ? 2.0 * posn * rows : 0.0));
+    snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" : bs ? "conv_h3d_kernel<%d, %d, %d, bsum>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
+    // (BSUM: + the producers' z tiles the epilogue reads - 2 bytes per value through the upsample, 4 for a skip or decimated row)
+    double bs_bytes = 0.0;
+    if (bs && bs->kind == 1) bs_bytes = posn * ((bs->z[0] ? 2.0 * bs->c0 : 0.0) + (bs->z[1] ? 4.0 * (rows - bs->c0) : 0.0));
+    if (bs && bs->kind == 2 && bs->z[0]) bs_bytes = posn * 4.0 * rows;
+    prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)) + (op ? 2.0 * posn * rows : 0.0) + bs_bytes);
     // (eval: BatchNorm scale / shift beside the bias in the block's table of per-row constants unless that costs the second block of a CU)
     a.epi_eval = (xrows && nseg == 1 && 2 * h3d_smem(nseg, mrep, bf, mtiles_p, 1) <= 160u * 1024u) ? 1 : 0;
-    const size_t smem = h3d_smem(nseg, mrep, bf, mtiles_p, a.epi_eval);
+    const size_t smem = h3d_smem(nseg, mrep, bf, mtiles_p, a.epi_eval, bs ? 1 : 0);
     const int nitems = a.ntiles * a.mblocks;
     // resident blocks: two per CU, one for the 16-segment tile (96 KB); a K-split layer whose items x splits fit them runs one item per block
     int gx = h3_grid_cap() / 2 * h3d_blocks_per_cu(nseg, mrep, bf) / ksplit;
@@ -148,7 +159,7 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     if (gx < 8) gx = 8;
     if (gx > nitems) gx = nitems;
     const dim3 grid((unsigned)gx, (unsigned)ksplit);
-    const int rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, op != nullptr);
+    const int rc = wunet_launch_conv_h3d(a, taps, mrep, nseg, grid, smem, st, bf != 0, op != nullptr, bs ? bs->kind : 0);
     prof_end(st);
     if (rc != 0) return fail(WUNET_E_ARG, "no conv_h3 kernel for taps=%d mrep=%d nseg=%d (rc %d)", taps, mrep, nseg, rc);
     return 0;

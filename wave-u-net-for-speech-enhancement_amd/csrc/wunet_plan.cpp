@@ -237,11 +237,12 @@ size_t h3w_part_stride(const LayerPlan& l)
 // dynamic LDS of one conv_h3d_kernel block: x tile [planes][4][NSEG * (256 / NSEG + 16)] + W sub-tile [planes][M_REP][5][64] pieces of 16 bytes
 // + the statistics hand-over
 // (un-segmented tiles: + the epilogue's per-row constants - bias, in eval mode also the BatchNorm scale / shift - of the mtp * 16 padded rows)
-size_t h3d_smem(int nseg, int mrep, int bf, int mtp, int eval)
+size_t h3d_smem(int nseg, int mrep, int bf, int mtp, int eval, int bsum)
 {
     const int npl = bf ? 1 : 2;
+    // (BSUM: four hand-over floats per row instead of two, no table of constants)
     return (size_t)(npl * 4 * nseg * (256 / nseg + 16) + npl * mrep * 5 * 64) * 16
-         + (size_t)(WUNET_WAVES * mrep * 32 + 4 + (nseg == 1 ? (eval ? 3 : 1) * mtp * 16 : 0)) * sizeof(float);
+         + (size_t)(WUNET_WAVES * mrep * (bsum ? 64 : 32) + 4 + ((nseg == 1 && !bsum) ? (eval ? 3 : 1) * mtp * 16 : 0)) * sizeof(float);
 }
 // blocks of that size a CU holds (launch bounds: two; the 16-segment tile's 96 KB: one) - the table of constants never costs the second block
 // (launch_conv_h3 leaves the eval part in global memory where it would)
@@ -445,6 +446,7 @@ void layout_workspace(wunet_ctx* c)
         l.mean = off; off += align64(l.cout);
         l.rstd = off; off += align64(l.cout);
         l.wl1 = off; off += align64(l.cout);
+        l.cst = off; off += align64((size_t)4 * l.cout);
         l.xin = off; if (i > 0 && !l.h3x) off += align64((size_t)B * l.cin * l.L);   // the conv's activated input, materialised once
     }
     // the operand pass of encoder-side layer i (decimation of its producer's activation) also writes that activation at full
@@ -545,6 +547,42 @@ void layout_workspace(wunet_ctx* c)
         l.gzh = off; off += align64((size_t)B * c8 * l.L * 4);      // per layer: the side stream reads it late
         l.gzl = off; off += align64((size_t)B * c8 * l.L * 4);
         l.gzp = off; off += 64;
+    }
+    // ---- BatchNorm-backward sums in the epilogue of the data gradient that produces dL/d(activation) (conv_h3d_kernel<.., BSUM>): for the
+    // layers whose consumers' data gradients run un-split on whole-row tiles of at least WUNET_BSUM samples (read when the context is
+    // planned).  Such a layer has no pass_a_kernel launch; its g_z is formed by gz_split_h3_kernel from the data gradients.
+    // OFF by default (0): measured at batch 64 x 16384 the step is 0.57 - 0.70 ms SLOWER with it (profiles/r6_bsum_ab.txt: pass A -0.48 ms,
+    // but the epilogue's loads sit exposed behind the K loop - no registers, no LDS to prefetch them - +0.65 ms on the data gradients, and the
+    // transposed upsample gathered inside gz_split_h3_kernel +0.47 ms).  Kept as a measured, tested alternative.
+    {
+        int bs_min = 0;
+        if (const char* e = getenv("WUNET_BSUM")) bs_min = atoi(e);
+        const int n = c->n, NL = c->NL;
+        auto dgrad_can = [&](const LayerPlan& q) {
+            return bs_min > 0 && q.h3d && q.L >= 256 && q.L >= bs_min && q.d.ksplit == 1 && (q.cin & 3) == 0 && !c->bf && !c->padded;
+        };
+        for (int p = 0; p < NL; ++p) { c->ly[p].bsum = 0; c->ly[p].bs_kind = 0; c->ly[p].bsp = 0; }
+        for (int p = 1; p + 1 < NL; ++p) {
+            LayerPlan& l = c->ly[p];
+            if (!l.h3d || l.L < 4) continue;            // (its own g_z on the split kernels: gz_split_h3_kernel's recompute modes)
+            if (p >= n) {                               // feeds the x2 upsample of the next decoder layer
+                const LayerPlan& q = c->ly[p + 1];
+                if (q.kind == LK_UPCAT && q.src0 == p && q.c0 == l.cout && (q.c0 & 3) == 0 && dgrad_can(q) && up_pairs_regular(l.L)) l.bsum = 1;
+            } else if (2 * n - p < NL) {                // an encoder layer: skip of decoder layer 2n - p, decimated into layer p + 1
+                const LayerPlan& dq = c->ly[2 * n - p];
+                const LayerPlan& eq = c->ly[p + 1];
+                if (dq.kind == LK_UPCAT && dq.src1 == p && (dq.c0 & 3) == 0 && dq.cin - dq.c0 == l.cout && eq.kind == LK_DECIM && eq.src0 == p &&
+                    eq.cin == l.cout && dgrad_can(dq) && dgrad_can(eq))
+                    l.bsum = 1;
+            }
+        }
+        for (int i = 1; i < NL; ++i) {
+            LayerPlan& q = c->ly[i];
+            if (!dgrad_can(q)) continue;
+            if (q.kind == LK_UPCAT && (c->ly[q.src0].bsum || c->ly[q.src1].bsum)) q.bs_kind = 1;
+            else if (q.kind == LK_DECIM && q.src0 >= 0 && c->ly[q.src0].bsum) q.bs_kind = 2;
+            if (q.bs_kind) { q.bsp = off; off += align64((size_t)q.cin * (((size_t)B * q.L + 255) / 256) * 4); }
+        }
     }
     c->h3_wb_halfs = wbh;
     c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
