@@ -541,6 +541,16 @@ def main():
         exchange = sync.describe(model._wunet_params(), 2 * args.layers + 1)
         exchange["allreduce_exposed_ms_per_rank"] = [round(float(t.item()), 4) for t in allr]
         exchange["measured_over_steps"] = len(ex)
+        # what every rank actually ran (a scaling record must explain itself: eager or one graph per step, which transport, the world size
+        # that transport reports, the device)
+        mine_desc = {"rank": rank, "step_launch": "one hipGraph replay per step" if use_graph else "eager launches",
+                     "transport": exchange["transport"], "world_seen": exchange["world"], "device": str(device)}
+        per_rank = [None] * world
+        if world > 1:
+            dist.all_gather_object(per_rank, mine_desc)
+        else:
+            per_rank = [mine_desc]
+        exchange["per_rank"] = per_rank
 
     roofline = None
     nprof = max(1, min(args.steps, 5))

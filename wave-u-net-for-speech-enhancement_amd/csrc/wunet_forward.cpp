@@ -382,7 +382,7 @@ int wunet_forward(wunet_ctx* c, const float* noisy, const float* const* params, 
         h.z = ws + l.z; h.a = ws + l.a; h.s = ws + l.s; h.in = noisy;
         h.wh = params[4 * c->NL]; h.bh = params[4 * c->NL + 1]; h.out = enhanced;
         h.B = c->B; h.C = c->ci; h.T = c->T; h.logT = ilog2(c->T);
-        long long blocks = ((long long)c->B * c->T + WUNET_THREADS - 1) / WUNET_THREADS;
+        long long blocks = ((long long)c->B * c->T / 4 + WUNET_THREADS - 1) / WUNET_THREADS;      // four samples per thread
         if (blocks > 4096) blocks = 4096;
         prof_begin(st, "head_fwd_kernel", 2.0 * c->B * c->T * (c->ci + 1.0), 4.0 * c->B * c->T * (c->ci + 2.0));
         WUNET_LAUNCH(head_fwd_kernel, dim3((unsigned)blocks), dim3(WUNET_THREADS), 0, st, h);

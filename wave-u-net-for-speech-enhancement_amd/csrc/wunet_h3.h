@@ -264,6 +264,11 @@ struct WgradH3dArgs {
     int B, Cin, Cout, XC8, GC8, L, logL, chunks_per_split;
     size_t part_stride;
     int cin_active;           // waves whose input channels start at or beyond it skip their MFMAs (= Cin; A/B switch: INT_MAX)
+    // XCD-aware walk (xcd_walk != 0; the grid is then 1-D): the nblocks * mblocks blocks that stream the SAME position range (one K split) -
+    // they re-read its g_z chunks once per input-channel block and its x chunks once per row block - get block ids 8 apart, i.e. the same
+    // XCD (block b runs on XCD b % 8: observed placement, for speed only) next to each other in dispatch order, and share those chunks in
+    // that XCD's L2; 8 consecutive splits interleave over the 8 XCDs.  Off: grid (ksplit, nblocks, mblocks), a split's blocks ksplit ids apart.
+    int xcd_walk, ksplit, nblocks, mblocks;
 };
 
 // TP = 64 with DB: chunks of 64 positions, double buffered within the LDS budget of ONE 128-position buffer - two blocks per CU AND
@@ -289,10 +294,18 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = lane >> 4, i16 = lane & 15;
     const int grp = TAPS == 15 ? wave >> 1 : wave;
     const int t0 = TAPS == 15 ? (wave & 1) * 8 : 0;
-    const int co0 = blockIdx.z * M_REP * 16, ci0 = blockIdx.y * CIB;
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (A.xcd_walk) {
+        const int nyz = A.nblocks * A.mblocks;
+        const int grp8 = (int)blockIdx.x / (8 * nyz), rem = (int)blockIdx.x - grp8 * 8 * nyz;
+        const int yz = rem >> 3;
+        bx = grp8 * 8 + (rem & 7); by = yz % A.nblocks; bz = yz / A.nblocks;
+        if (bx >= A.ksplit) return;                  // (the last group of 8 splits may be short)
+    }
+    const int co0 = bz * M_REP * 16, ci0 = by * CIB;
     const int L = A.L;
     const long long nchunks = ((long long)A.B * L) / TP;
-    const long long kbeg = (long long)blockIdx.x * A.chunks_per_split;
+    const long long kbeg = (long long)bx * A.chunks_per_split;
     long long kend = kbeg + A.chunks_per_split;
     if (kend > nchunks) kend = nchunks;
 
@@ -418,8 +431,8 @@ __global__ __launch_bounds__(WUNET_THREADS, ((DB && TP == 128) ? 1 : 2)) void wg
 #undef WUNET_WH3D_DMA
 
     const float inv = A.sc[1], inv2 = A.sc2[1];
-    float* part = A.part + (size_t)blockIdx.x * A.part_stride
-                + ((((size_t)blockIdx.z * gridDim.y + blockIdx.y) * WUNET_WAVES + wave) * (M_REP * TW)) * 256 + lane * 4;
+    float* part = A.part + (size_t)bx * A.part_stride
+                + ((((size_t)bz * (A.xcd_walk ? (unsigned)A.nblocks : gridDim.y) + by) * WUNET_WAVES + wave) * (M_REP * TW)) * 256 + lane * 4;
 #pragma unroll
     for (int mt = 0; mt < M_REP; ++mt)
 #pragma unroll

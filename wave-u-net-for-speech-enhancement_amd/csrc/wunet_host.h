@@ -85,6 +85,7 @@ struct LayerPlan {
     int h3x;                      // the conv input exists only in the split layout (no fp32 xin)
     int skip_from;                // decoder layer: > 0 = its skip half is written by the operand pass of encoder-side layer skip_from
     int h3w, h3w_mrep, h3w_mblocks, h3w_nblocks, h3w_ksplit, h3w_cps, h3w_tp;   // weight gradient uses wgrad_h3_kernel
+    int h3w_xcd;                  // wgrad_h3d_kernel walks its blocks XCD-aware (the blocks of one K split on one XCD)
     int h3u, h3u_train;           // conv_h3u_kernel (operand pass fused into the conv's loader waves) runs the eval / also the training forward
     int feeds_h3;                 // the layer's activation is the (or a) source of a conv input that exists in the split layout
     size_t xh, xl, xzp;           // split activated input (float offsets): hi plane, lo plane right behind it, then 16 zero bytes (DMA pad)

@@ -217,12 +217,17 @@ int launch_wgrad_h3(const LayerPlan& l, const wunet_half* xh, const wunet_half* 
         a.XC8 = (l.cin + 7) / 8; a.GC8 = (l.cout + 7) / 8; a.L = l.L; a.logL = l.logL;
         a.chunks_per_split = l.h3w_cps; a.part_stride = h3w_part_stride(l);
         a.cin_active = l.cin;
+        a.ksplit = l.h3w_ksplit; a.nblocks = l.h3w_nblocks; a.mblocks = l.h3w_mblocks;
+        // the blocks of one K split on one XCD where the planner found room (plan_h3_wgrad; WgradH3dArgs::xcd_walk)
+        a.xcd_walk = l.h3w_xcd;
         snprintf(pname, sizeof pname, bf ? "wgrad_h3d_kernel<%d, %d, bf16>" : "wgrad_h3d_kernel<%d, %d>", l.taps, l.h3w_mrep);
         prof_begin(st, pname, 2.0 * posn * l.cout * l.cin * l.taps, 4.0 * posn * (l.cout + l.cin));
         // two blocks per CU with a single buffer where the registers allow it (two independent blocks hide each other's
         // waits: +18-28 % on those kernels), else one block with double-buffered tiles
         const bool db = !((l.taps == 5 && l.h3w_mrep <= 4) || (l.taps == 15 && l.h3w_mrep <= 3));
-        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, grid, db ? smem_d : smem_d / 2, st, bf != 0, tp);
+        const int nyz = l.h3w_nblocks * l.h3w_mblocks;
+        const dim3 grid_x((unsigned)(((l.h3w_ksplit + 7) / 8) * 8 * nyz));
+        rc = wunet_launch_wgrad_h3d(a, l.taps, l.h3w_mrep, db, a.xcd_walk ? grid_x : grid, db ? smem_d : smem_d / 2, st, bf != 0, tp);
     } else {
         WgradH3Args a{};
         a.xh = xh; a.xl = xl; a.gh = gh; a.gl = gl; a.sc = sc; a.sc2 = sc2; a.part = part; a.B = B; a.Cin = l.cin; a.Cout = l.cout;

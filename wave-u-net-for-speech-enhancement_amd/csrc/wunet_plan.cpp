@@ -342,6 +342,22 @@ void plan_h3_wgrad(LayerPlan& l, int B)
     if (ks < 1) ks = 1;
     const long long chunks = ((long long)B * l.L + l.h3w_tp - 1) / l.h3w_tp;
     if (ks > chunks) ks = chunks;
+    // XCD-aware walk of wgrad_h3d_kernel (WgradH3dArgs::xcd_walk): the nyz blocks of one K split share an XCD, so an XCD hosts
+    // ceil(ks / 8) * nyz blocks - they must fit its share of the resident slots, else some blocks wait for a second round (measured:
+    // wgrad_h3d_kernel<5, 3> 404 -> 493 us per step with 66 / 72 blocks on an XCD of 64 slots).  The split count is trimmed to fit when
+    // that costs at most 6 % of the blocks; otherwise the layer keeps the 3-D grid.  WUNET_WGRAD_XCD=0: off (A/B switch).
+    {
+        static const bool xcd_off = getenv("WUNET_WGRAD_XCD") != nullptr && atoi(getenv("WUNET_WGRAD_XCD")) == 0;
+        const long long nyz = (long long)l.h3w_mblocks * l.h3w_nblocks, per_xcd = slots / 8;
+        l.h3w_xcd = 0;
+        if (!xcd_off && nyz > 1 && l.L >= 128) {
+            if (((ks + 7) / 8) * nyz <= per_xcd) l.h3w_xcd = 1;
+            else {
+                const long long ks8 = (per_xcd / nyz) * 8;
+                if (ks8 >= 8 && ks8 * 100 >= ks * 94) { ks = ks8; l.h3w_xcd = 1; }
+            }
+        }
+    }
     l.h3w_cps = (int)((chunks + ks - 1) / ks);
     l.h3w_ksplit = (int)((chunks + l.h3w_cps - 1) / l.h3w_cps);
 }
