@@ -162,10 +162,10 @@ def test_fused_loaders_on_ragged_and_padded_shapes(pkg, dev, B, T):
 
 def test_bn_backward_sums_in_the_data_gradient_epilogue(pkg, dev):
     """conv_h3d_kernel<.., BSUM> on the hardware (off by default - profiles/r6_bsum_ab.txt - so the planner switch WUNET_BSUM is set here): a
-    training step at batch 16 x 16384 with the BatchNorm-backward sums taken in the data gradients' epilogues from 1024 samples up equals the
+    training step at batch 64 x 16384 with the BatchNorm-backward sums taken in the data gradients' epilogues from 1024 samples up equals the
     same step with pass_a_kernel to the rounding of another summation order (1e-5 of each gradient tensor's maximum), the kernels really run
     (profile names), and pass A is gone for those layers (unet_basic.py:12-13,25-26,86,93-95 backwards)."""
-    B, T = 16, 16384
+    B, T = 64, 16384
     noisy, clean = plan.golden_batch(B, T, 9)
     sd = plan.golden_state(N, CI, 0)
     eng_mod = importlib.import_module(PKG_NAME + ".engine")

@@ -333,7 +333,7 @@ struct HeadFwdArgs {
     int B, C, T, logT;
 };
 
-// One thread = 4 consecutive samples; the channels are walked eight at a time with all eight 16-byte loads issued before the first is used
+// One thread = 4 consecutive samples; the channels are walked 24 (then eight) at a time with all the 16-byte loads of a group issued before the first is used
 // (rounds 1 - 5: one sample per thread and a run-time loop over the channels - 24 dependent 4-byte round trips per thread, 2.3 - 2.7 TB/s;
 // same order of additions, bit-identical results).
 static __global__ __launch_bounds__(WUNET_THREADS) void head_fwd_kernel(HeadFwdArgs A)
@@ -347,6 +347,17 @@ static __global__ __launch_bounds__(WUNET_THREADS) void head_fwd_kernel(HeadFwdA
         const wunet_f4 xin = wunet_ld4(A.in + p);
         wunet_f4 acc = wunet_f4{bh, bh, bh, bh};
         int c = 0;
+        for (; c + 24 <= A.C; c += 24) {           // (the reference's 24 channels: every load of the thread in flight at once)
+            wunet_f4 v[24];
+#pragma unroll
+            for (int e = 0; e < 24; ++e) v[e] = wunet_ld4(zr + (size_t)(c + e) * A.T);
+#pragma unroll
+            for (int e = 0; e < 24; ++e) {
+                const float av = A.a[c + e], sv = A.s[c + e], wv = A.wh[c + e];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += wv * wunet_lrelu(av * v[e][j] + sv);
+            }
+        }
         for (; c + 8 <= A.C; c += 8) {
             wunet_f4 v[8];
 #pragma unroll
