@@ -249,6 +249,30 @@ inline float wunet_row16_sum(float v)
     return v;
 }
 
+// lane i of a 16-lane row receives lane i - 1's (shr) / lane i + 1's (shl) value; the row's first / last lane receives 0
+inline float wunet_row16_shr1(float v)
+{
+    emu::FiberState& f = emu::cur_fiber();
+    emu::BlockState& blk = emu::cur_block();
+    const int lane = f.tidx.x & 63, wave = f.tidx.x >> 6, par = f.op_parity;
+    f.op_parity ^= 1;
+    blk.wave_a[wave][par][lane] = v;
+    emu::wave_barrier();
+    return (lane & 15) ? blk.wave_a[wave][par][lane - 1] : 0.0f;
+}
+inline float wunet_row16_shl1(float v)
+{
+    emu::FiberState& f = emu::cur_fiber();
+    emu::BlockState& blk = emu::cur_block();
+    const int lane = f.tidx.x & 63, wave = f.tidx.x >> 6, par = f.op_parity;
+    f.op_parity ^= 1;
+    blk.wave_a[wave][par][lane] = v;
+    emu::wave_barrier();
+    return (lane & 15) != 15 ? blk.wave_a[wave][par][lane + 1] : 0.0f;
+}
+
+inline float wunet_lane_swap1(float v) { return wunet_shfl_xor(v, 1); }
+
 inline float wunet_row16_max(float v)
 {
     for (int m = 1; m < 16; m <<= 1) v = std::fmax(v, wunet_shfl_xor(v, m));

@@ -278,6 +278,7 @@ def test_bn_backward_sums_in_the_data_gradient_epilogue(monkeypatch, n, ci, B, T
     eng_mod = importlib.import_module(PKG_NAME + ".engine")
     lib_mod = importlib.import_module(PKG_NAME + "._lib")
     monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")          # (small shapes: un-split data gradients, as at the BASELINE size)
+    monkeypatch.setenv("WUNET_UPT", "0")                 # (against the classic gradient assembly: pass_a_kernel<UP> on full-resolution rows)
     if order:
         monkeypatch.setenv("WUNET_H3D_ORDER", order)
     sd = plan.golden_state(n, ci, 0)
@@ -305,6 +306,46 @@ def test_bn_backward_sums_in_the_data_gradient_epilogue(monkeypatch, n, ci, B, T
     for k, g in got["256"][1].items():
         r = got["0"][1][k]
         assert np.abs(g - r).max() <= 2e-5 * max(np.abs(r).max(), 1e-12), k
+
+
+@pytest.mark.parametrize("n,ci,B,T,order", [(2, 24, 2, 1024, ""), (3, 24, 3, 2048, ""), (3, 20, 2, 1024, "432")])
+def test_upsample_transpose_in_the_data_gradient_epilogue(monkeypatch, n, ci, B, T, order):
+    """conv_h3d_kernel<.., 3> (UPT): a decoder layer's data gradient stores the rows of the upsampled half of its input already pulled back
+    through the x2 upsample (the transposed upsample on the accumulators: neighbour lanes by DPP, neighbour waves through LDS, neighbour
+    tiles through the edge terms the reader adds), the producer's gradient assembly is the elementwise pass_a_kernel<UPH> and its g is
+    re-formed by gz_split_h3_kernel from the same half-resolution array.  Against the float64 oracle and against the same step with the
+    full-resolution rows + pass_a_kernel<UP> (WUNET_UPT=0): the same multiply-adds in the same order except at the two edge inputs of a
+    128-input tile."""
+    import ctypes
+    from test_scale_robustness import errors, run_step
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")          # (small shapes: un-split data gradients, as at the BASELINE size)
+    if order:
+        monkeypatch.setenv("WUNET_H3D_ORDER", order)
+    sd = plan.golden_state(n, ci, 0)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, True, "mse", precision="f64")
+    got = {}
+    for v in ("1", "0"):
+        monkeypatch.setenv("WUNET_UPT", v)
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
+        eng.lib.wunet_profile_enable(1)
+        out, grads = run_step(eng, sd, n, ci, noisy, clean)
+        buf = ctypes.create_string_buffer(1 << 16)
+        eng.lib.wunet_profile_collect(buf, len(buf))
+        eng.lib.wunet_profile_enable(0)
+        names = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().strip().splitlines()}
+        got[v] = (out, grads, names)
+        oe, ge = errors(out, grads, ref)
+        assert oe < 2e-5 and ge < 3e-4, (v, oe, ge)
+    on, off = got["1"][2], got["0"][2]
+    n_upt = sum(c for k, c in on.items() if k.endswith(", upt>"))
+    assert n_upt >= 2 and on.get("pass_a_kernel<UPH>", 0) == n_upt and not any(k.endswith(", upt>") or k == "pass_a_kernel<UPH>" for k in off)
+    assert on.get("pass_a_kernel<UP>", 0) + n_upt == off["pass_a_kernel<UP>"]
+    for k, g in got["1"][1].items():
+        r = got["0"][1][k]
+        assert np.abs(g - r).max() <= 1e-5 * max(np.abs(r).max(), 1e-12), k
 
 
 def test_fused_adam_matches_torch(emu_engine):

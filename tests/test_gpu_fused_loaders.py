@@ -171,7 +171,7 @@ def test_bn_backward_sums_in_the_data_gradient_epilogue(pkg, dev):
     eng_mod = importlib.import_module(PKG_NAME + ".engine")
     res = {}
     for bs in ("1024", "0"):
-        env = {"WUNET_BSUM": bs}
+        env = {"WUNET_BSUM": bs, "WUNET_UPT": "0"}       # (both arms on full-resolution rows: the comparison is against pass_a_kernel<UP>)
         with _planned_under(env):
             eng = eng_mod.Engine()
             m = pkg.Model(n_layers=N, channels_interval=CI)
@@ -194,5 +194,44 @@ def test_bn_backward_sums_in_the_data_gradient_epilogue(pkg, dev):
     assert sum(v for k, v in on.items() if k.endswith(", bsum>")) >= 2 and not any(k.endswith(", bsum>") for k in off), sorted(on)
     assert on.get("pass_a_kernel<UP>", 0) < off["pass_a_kernel<UP>"] and on.get("pass_a_kernel<ENC>", 0) < off["pass_a_kernel<ENC>"]
     for k, g in res["1024"][1].items():
+        r = res["0"][1][k]
+        assert (g - r).abs().max().item() <= 1e-5 * max(r.abs().max().item(), 1e-12) + 1e-9, k
+
+
+def test_upsample_transpose_in_the_data_gradient_epilogue(pkg, dev):
+    """conv_h3d_kernel<.., 3> (UPT, the default planner at the BASELINE size) on the hardware - DPP row shifts, the LDS hand-over between the
+    four waves, the tile-edge terms: a training step at batch 64 x 16384 equals the step with full-resolution rows + pass_a_kernel<UP>
+    (WUNET_UPT=0) to the rounding of the edge inputs' other summation order, the kernels run, pass_a_kernel<UP> is gone for those layers
+    (model/unet_basic.py:93 backwards)."""
+    B, T = 64, 16384
+    noisy, clean = plan.golden_batch(B, T, 9)
+    sd = plan.golden_state(N, CI, 0)
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    res = {}
+    for v in ("1", "0"):
+        with _planned_under({"WUNET_UPT": v}):
+            eng = eng_mod.Engine()
+            m = pkg.Model(n_layers=N, channels_interval=CI)
+            m.load_state_dict({k: torch.from_numpy(a.copy()) for k, a in sd.items()})
+            m.to(dev).train()
+            crit = pkg.smooth_l1_loss()
+            m._engine_override = crit._engine_override = eng
+            eng.lib.wunet_profile_enable(1)
+            try:
+                out = m(torch.from_numpy(noisy).to(dev))
+                crit(torch.from_numpy(clean).to(dev), out).backward()
+                torch.cuda.synchronize()
+                buf = ctypes.create_string_buffer(1 << 16)
+                eng.lib.wunet_profile_collect(buf, len(buf))
+            finally:
+                eng.lib.wunet_profile_enable(0)
+            names = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().strip().splitlines()}
+            res[v] = (names, {k: p.grad.clone() for k, p in m.named_parameters()})
+    on, off = res["1"][0], res["0"][0]
+    n_upt = sum(c for k, c in on.items() if k.endswith(", upt>"))
+    assert n_upt >= 5 and on.get("pass_a_kernel<UPH>", 0) == n_upt, sorted(on)
+    assert not any(k.endswith(", upt>") or k == "pass_a_kernel<UPH>" for k in off)
+    assert on.get("pass_a_kernel<UP>", 0) + n_upt == off["pass_a_kernel<UP>"]
+    for k, g in res["1"][1].items():
         r = res["0"][1][k]
         assert (g - r).abs().max().item() <= 1e-5 * max(r.abs().max().item(), 1e-12) + 1e-9, k

@@ -38,6 +38,7 @@ int wunet_launch_conv_h3d(const ConvH3Args& a, int taps, int mrep, int nseg, dim
 {
     WUNET_XCASE_BSUM(5, 2, 1) WUNET_XCASE_BSUM(5, 3, 1) WUNET_XCASE_BSUM(5, 4, 1)
     WUNET_XCASE_BSUM(15, 2, 2) WUNET_XCASE_BSUM(15, 3, 2) WUNET_XCASE_BSUM(15, 4, 2)
+    WUNET_XCASE_BSUM(5, 2, 3) WUNET_XCASE_BSUM(5, 3, 3) WUNET_XCASE_BSUM(5, 4, 3)           // UPT: the upsampled rows stored at the producer's resolution
     if (bsum) return -5;
     WUNET_XCASE_EVOP(2) WUNET_XCASE_EVOP(3) WUNET_XCASE_EVOP(4)
     if (evop) return -4;

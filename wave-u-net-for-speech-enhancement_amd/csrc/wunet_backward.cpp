@@ -100,10 +100,12 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         // mode) from them instead of written here and read back (WUNET_NO_ENC_GZ=1: A/B switch)
         static const bool no_enc_gz = getenv("WUNET_NO_ENC_GZ") != nullptr;
         const bool enc_in_gz = i > 0 && i < n && l.h3d && !fuse && !tiny && !dx_stays_split(c, i + 1) && !no_enc_gz;
+        // a layer behind an upsample whose consumer's data gradient arrives at this layer's resolution (UPT, planned by layout_workspace)
+        const bool uph = !bsum && i >= n && i + 1 < NL && c->ly[i + 1].upt && l.h3d && !fuse && !tiny;
         if (!bsum) {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
             const double pe = (double)c->B * l.cout * l.L;
             const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : "pass_a_kernel<ENC>";
-            prof_begin(st, nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : i >= n ? 16.0 : (enc_in_gz ? 10.0 : 14.0)) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
+            prof_begin(st, uph ? "pass_a_kernel<UPH>" : nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : uph ? 8.0 : i >= n ? 16.0 : (enc_in_gz ? 10.0 : 14.0)) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
         }
         if (bsum) {
         } else if (i == NL - 1) {
@@ -114,6 +116,14 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             WUNET_CHECK_LAUNCH();
             WUNET_LAUNCH(rows_sum_kernel, dim3(c->ci), dim3(WUNET_THREADS), 0, st,
                          (const float*)(ws + c->hpart2_off), l.a_split, c->ci, grads[4 * NL], c->ci, grads[4 * NL + 1]);
+        } else if (i >= n && uph) {
+            // the next decoder layer's data gradient arrived at THIS resolution (conv_h3d_kernel<.., 3>): elementwise; g is not stored -
+            // gz_split_h3_kernel forms it again from the same two arrays (UPH mode)
+            const LayerPlan& nx = c->ly[i + 1];
+            p.g0 = ws + nx.dxh; p.sp = ws + nx.usp; p.ntiles = (int)(((size_t)c->B * nx.L + 255) / 256); p.tpr = l.L >> 7;
+            p.gpre = nullptr;
+            WUNET_LAUNCH(pass_a_kernel<A_UPH>, ga, dim3(WUNET_THREADS), 0, st, p);
+            prof_end(st);
         } else if (i >= n) {
             const LayerPlan& nx = c->ly[i + 1];
             p.g0 = ws + nx.dx; p.Cg0 = nx.cin;
@@ -179,6 +189,10 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     prof_begin(st, "gz_split_h3_kernel", 0.0, (double)c->B * l.cout * l.L * ((head_in_gz ? 4.0 : enc_in_gz ? 10.0 : up_in_gz ? 12.0 : 8.0) + (c->bf ? 2.0 : 4.0)));
                     GzHeadArgs hd{};
                     if (head_in_gz) { hd.gh = ws + c->gh_off; hd.wh = params[4 * NL]; hd.a = ws + l.a; hd.s = ws + l.s; }
+                    if (uph) {
+                        const LayerPlan& q = c->ly[i + 1];
+                        hd.gq = ws + q.dxh; hd.a = ws + l.a; hd.s = ws + l.s;
+                    }
                     if (up_in_gz) {
                         const LayerPlan& q = c->ly[i + 1];
                         hd.gu = ws + q.dx; hd.Cg0 = q.cin; hd.up_scale = (float)(l.Lt - 1) / (float)(2 * l.Lt - 1); hd.a = ws + l.a; hd.s = ws + l.s;
@@ -286,6 +300,12 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             const bool split = l.d.ksplit > 1;
             // (BSUM: the epilogue also takes the BatchNorm-backward sums of the layers that produced this layer's input rows)
             ConvH3Bsum bs{};
+            // (UPT: the rows of the upsampled half leave at the producer's resolution - the producer's gradient assembly is then elementwise)
+            const bool upt = l.upt && !split && c->ly[l.src0].h3d;
+            if (upt) {
+                bs.kind = 3; bs.c0 = l.c0; bs.up_scale = (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1);
+                bs.uh_out = ws + l.dxh; bs.uh_spill = ws + l.usp;
+            }
             if (l.bs_kind && !split) {
                 const LayerPlan& pa = c->ly[l.src0];
                 bs.kind = l.bs_kind; bs.c0 = l.c0; bs.up_scale = (float)(l.Lt / 2 - 1) / (float)(l.Lt - 1); bs.part = ws + l.bsp;
@@ -301,7 +321,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                                     reinterpret_cast<const wunet_half*>(ws + c->h3_wb_lo) + l.h3d_wpk, nullptr, sc,
                                     ws + c->fslot_off + (size_t)WUNET_SLOT_FLOATS * i + 2,
                                     split ? ws + c->spart_off : ws + l.dx, nullptr, c->B, l.cin, l.cout, l.h3d_nch, l.L, st, ws + l.gzp, nullptr, nullptr,
-                                    nullptr, c->bf, l.h3d_ntt, nullptr, (bs.z[0] || bs.z[1]) ? &bs : nullptr);
+                                    nullptr, c->bf, l.h3d_ntt, nullptr, (upt || bs.z[0] || bs.z[1]) ? &bs : nullptr);
             if (rc) return rc;
             WUNET_CHECK_LAUNCH();
             if (split && !dx_stays_split(c, i)) {

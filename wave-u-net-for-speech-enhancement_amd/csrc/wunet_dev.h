@@ -46,6 +46,20 @@ __device__ __forceinline__ float wunet_row16_max(float v)
 #undef WUNET_DPP_MAX
     return v;
 }
+// lane i of a 16-lane row receives lane i - 1's (shr) / lane i + 1's (shl) value by one DPP move; the row's first / last lane receives 0
+__device__ __forceinline__ float wunet_row16_shr1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));      // row_shr:1
+}
+__device__ __forceinline__ float wunet_row16_shl1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true));      // row_shl:1
+}
+// the value of lane ^ 1 (DPP quad_perm [1, 0, 3, 2])
+__device__ __forceinline__ float wunet_lane_swap1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+}
 // 16-byte staging registers are the NATIVE vector type: arrays of HIP's float4 struct carried across loop
 // iterations were demoted to scratch memory by hipcc (global_load -> vmcnt(0) -> scratch_store), which
 // silently serialised the software pipeline.

@@ -435,7 +435,21 @@ static __global__ __launch_bounds__(WUNET_THREADS) void rows_sum_kernel(const fl
 //   A_UP   : g_y[b,c,i] = sum_j w(j->i) dX[b,c,j], dX of the next decoder layer at 2L, upsample^T
 //   A_ENC  : g_y[b,c,l] = dXdec[b, coff+c, l] + (l even ? dXenc[b,c,l/2] : 0)   (skip + decimation^T)
 // grid = (C, nsplit); part[split][C][2].
-enum { A_HEAD = 0, A_UP = 1, A_ENC = 2 };
+//   A_UPH  : g_y[b,c,i] = dXh[b,c,i] (+ the tile-edge terms): the next decoder layer's data gradient arrives already pulled back through
+//            the upsample (conv_h3d_kernel<.., 3>, ConvH3Args::uh_*) - a plain elementwise pass
+enum { A_HEAD = 0, A_UP = 1, A_ENC = 2, A_UPH = 3 };
+
+// The tile-edge terms of a half-resolution data gradient (ConvH3Args::uh_spill [2][C][ntiles]; a tile = 128 inputs of one row): input l, the
+// first of a tile, is owed sp[0][c][tile - 1]; the last of a tile sp[1][c][tile + 1].  g: the four inputs l .. l + 3 (l a multiple of 4) of
+// channel c, item b; tpr = tiles per row.  Row ends are owed nothing (the terms there are exact zeros, but the neighbour tile may not exist).
+// pass_a_kernel<A_UPH> - one channel per thread, no loads to batch - adds them and writes the two completed values back into the array, so the
+// second reader (gz_split_h3_kernel's UPH mode, eight channels per thread) reads finished values with nothing conditional among its loads.
+__device__ __forceinline__ void wunet_uph_edges(const float* sp, int C, int ntiles, int tpr, int b, int c, int l, int L, float* gq_at_l, float& g_first, float& g_last)
+{
+    const int tile = b * tpr + (l >> 7);
+    if ((l & 127) == 0 && l > 0) { g_first += sp[(size_t)c * ntiles + tile - 1]; gq_at_l[0] = g_first; }
+    if ((l & 127) == 124 && l + 4 < L) { g_last += sp[((size_t)C + c) * ntiles + tile + 1]; gq_at_l[3] = g_last; }
+}
 
 // Transposed x2 upsample of ONE row, four inputs at a time, for callers that walk several channels at the same positions (gz_split_h3_kernel's
 // UP mode: 8 channels per thread): the coordinates of outputs 2l - 1 .. 2l + 8 once (wunet_upT_coords), then per row the ten data-gradient
@@ -502,7 +516,7 @@ struct PassAArgs {
     float* part;         // [nsplit][C][2]
     float* pmax;         // nullptr or [nsplit][C][2]: max |g_pre|, max |z - mean| (bound of |g_z| for the fp16-split scale)
     float* hpart;        // HEAD: [nsplit][C] partial head-weight gradients  sum gh * act(z_c)  (same pass over z and gh)
-    const float* g0;     // HEAD: gh [B][L];  UP: dX [B][Cg0][2L];  ENC: dXdec [B][Cg0][L]
+    const float* g0;     // HEAD: gh [B][L];  UP: dX [B][Cg0][2L];  ENC: dXdec [B][Cg0][L];  UPH: dXh [B][C][L] (its tile-edge values are completed IN PLACE)
     const float* g1;     // HEAD: wh;         ENC: dXenc [B][C][L/2]
     int Cg0;             // channel count of the g0 tensor
     int g1_splits;       // ENC: > 1 - g1 points at the split-K partials of the data gradient (g1_stride floats apart): this pass is their
@@ -512,6 +526,8 @@ struct PassAArgs {
     float up_scale;      // UP: (float)(Lt-1)/(2Lt-1)
     int swap;            // grid = (splits, C) instead of (C, splits)
     int Lt;              // samples of a row that exist (<= L, the power-of-two row stride; PrepArgs::Lt): the padding gets no gradient
+    const float* sp;     // UPH: the tile-edge terms [2][C][ntiles] (g0 = dXh [B][C][L])
+    int ntiles, tpr;     // UPH: tiles of the consumer's data gradient, tiles per row (L / 128)
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
     const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
@@ -549,6 +565,11 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
                 g[j] = wh * gh[j];
                 s3 += (double)(gh[j] * wunet_lrelu(a * z[j] + s));      // d(head weight of channel c)
             }
+        } else if (MODE == A_UPH) {
+            float* const gq = const_cast<float*>(A.g0) + ((size_t)b * A.C + c) * A.L + l;
+            const wunet_f4 gp = wunet_ld4(gq);
+            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2]; g[3] = gp[3];
+            wunet_uph_edges(A.sp, A.C, A.ntiles, A.tpr, b, c, l, A.L, gq, g[0], g[3]);
         } else if (MODE == A_ENC) {
             const wunet_f4 gd = wunet_ld4(A.g0 + ((size_t)b * A.Cg0 + A.coff + c) * A.L + l);
             const float* ge = A.g1 + ((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1);

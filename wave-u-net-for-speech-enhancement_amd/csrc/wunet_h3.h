@@ -81,8 +81,17 @@ struct ConvH3Args {
     const float* bs_cst[2];                       // their BatchNorm constants [C][4] = {a, s, mean, rstd} (bn_finalize_core writes the table)
     int bs_C[2];                                  // channel counts of the producers (row strides of their z)
     int bs_c0;                                    // first row of producer B
-    float bs_up_scale;                            // BSUM = 1: (float)(L/2 - 1) / (float)(L - 1)
+    float bs_up_scale;                            // BSUM = 1, 3: (float)(L/2 - 1) / (float)(L - 1)
     float* bs_part;
+    // BSUM = 3 ("UPT", training backward of a decoder layer, un-split whole-row tiles): the rows < bs_c0 - the gradient w.r.t. the UPSAMPLED
+    // half of the conv input (model/unet_basic.py:93 backwards) - leave the kernel already pulled back through the x2 upsample: the transpose
+    // of ATen's upsample_linear1d (fp32 coordinates, pass_a_kernel<A_UP>'s arithmetic in its order) is applied to the accumulators, a lane's
+    // four outputs p0 .. p0 + 3 making the two inputs p0 / 2, p0 / 2 + 1 with one value from each neighbour lane (a DPP move; across the
+    // four waves through LDS), and uh_out [B][bs_c0][L/2] is written instead of those rows of `out` - half the bytes written here, half the
+    // bytes read by the gradient assembly, which becomes a plain elementwise pass.  What a tile owes its neighbour TILES (the first / last
+    // input of a tile gets one term from the tile before / behind it) goes to uh_spill [2][bs_c0][ntiles]: [0] = the term for the next
+    // tile's first input, [1] = the term for the previous tile's last input; the reader adds them (2 of 128 positions).
+    float* uh_out; float* uh_spill;
 };
 
 // ---------------------------------------------------------------------------- weight gradient

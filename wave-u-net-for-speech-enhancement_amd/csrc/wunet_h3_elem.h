@@ -294,6 +294,7 @@ struct GzHeadArgs {
     const float* gh; const float* wh; const float* a; const float* s;      // HEAD (gh != nullptr); a, s also ENC and UP
     const float* gd; const float* ge; int Cg0, coff;                        // ENC (gd != nullptr): dXdec [B][Cg0][L], dXenc [B][C][L/2]
     const float* gu; float up_scale;                                        // UP (gu != nullptr): dX [B][Cg0][2L]; (float)(Lt-1)/(2Lt-1)
+    const float* gq;                                                        // UPH (gq != nullptr): dXh [B][C][L], completed by pass_a_kernel<A_UPH>
 };
 #define WUNET_GZ_FIN_LOADS 1536   // (sweep 1152 / 2048 / 3100 / all: 5.41 / 5.42 / 5.46 / 5.50 ms per step - beyond the 512-sample level the prologue costs more than the launch)
 #define WUNET_GZ_FIN_C 512
@@ -378,6 +379,30 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
             if (H.gh) gh4 = wunet_ld4(H.gh + (size_t)b * L + 4 * l4);
             WunetUpT U;
             if (H.gu) wunet_upT_coords(4 * l4, Lt, H.up_scale, U);
+            // the eight channels' constants as 16-byte loads (k1 .. k3 and the BatchNorm scale / shift of the recompute modes: five arrays whose
+            // rows are padded to 64 floats - the loads past C stay inside them and their values are selected away): 10 load instructions per
+            // thread instead of 40 one-float loads beside the 16 that carry data
+            float kA[8], kB[8], kD[8], hA[8], hS[8];
+            {
+                const int c0_ = c8 * 8;
+                if (FIN) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { kA[e] = ks[c0_ + e]; kB[e] = ks[WUNET_GZ_FIN_C + c0_ + e]; kD[e] = ks[2 * WUNET_GZ_FIN_C + c0_ + e]; }
+                } else {
+                    const wunet_f4 a0 = wunet_ld4(k1 + c0_), a1 = wunet_ld4(k1 + c0_ + 4), b0 = wunet_ld4(k2 + c0_), b1 = wunet_ld4(k2 + c0_ + 4);
+                    const wunet_f4 d0 = wunet_ld4(k3 + c0_), d1 = wunet_ld4(k3 + c0_ + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { kA[e] = a0[e]; kA[4 + e] = a1[e]; kB[e] = b0[e]; kB[4 + e] = b1[e]; kD[e] = d0[e]; kD[4 + e] = d1[e]; }
+                }
+                if (H.a) {
+                    const wunet_f4 a0 = wunet_ld4(H.a + c0_), a1 = wunet_ld4(H.a + c0_ + 4), s0 = wunet_ld4(H.s + c0_), s1 = wunet_ld4(H.s + c0_ + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { hA[e] = a0[e]; hA[4 + e] = a1[e]; hS[e] = s0[e]; hS[4 + e] = s1[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hA[e] = hS[e] = 0.0f;
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int c = c8 * 8 + e;
@@ -386,8 +411,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                 const int cc = ok ? c : 0;
                 const wunet_f4 zv = wunet_ld4(z + o);
                 wunet_f4 gv;
+                const float ha = hA[e], hs = hS[e];
                 if (H.gh) {
-                    const float wh = H.wh[cc], ha = H.a[cc], hs = H.s[cc];
+                    const float wh = H.wh[cc];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float t = wh * gh4[j];
@@ -397,19 +423,23 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                 } else if (H.gd) {
                     const wunet_f4 d4 = wunet_ld4(H.gd + ((size_t)b * H.Cg0 + H.coff + cc) * L + 4 * l4);
                     const float2 e2 = *reinterpret_cast<const float2*>(H.ge + ((size_t)b * C + cc) * (L >> 1) + 2 * l4);
-                    const float ha = H.a[cc], hs = H.s[cc];
                     gv[0] = d4[0] + e2.x; gv[1] = d4[1]; gv[2] = d4[2] + e2.y; gv[3] = d4[3];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(ha * zv[j] + hs > 0.0f)) gv[j] *= WUNET_SLOPE;
+                } else if (H.gq) {
+                    // (a layer behind an upsample whose consumer's data gradient arrives at this resolution: pass_a_kernel<A_UPH>'s arithmetic)
+                    gv = wunet_ld4(H.gq + o);        // (tile-edge values completed in place by pass_a_kernel<A_UPH>)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         if (!(ha * zv[j] + hs > 0.0f)) gv[j] *= WUNET_SLOPE;
                 } else if (H.gu) {
                     float gg[4];
                     wunet_upT_row(H.gu + ((size_t)b * H.Cg0 + cc) * (size_t)(2 * L), 4 * l4, 2 * L, 2 * Lt, Lt, H.up_scale, U, gg);
-                    const float ha = H.a[cc], hs = H.s[cc];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) gv[j] = (ha * zv[j] + hs > 0.0f) ? gg[j] : gg[j] * WUNET_SLOPE;
                 } else gv = wunet_ld4(g + o);
-                const float a = FIN ? ks[cc] : k1[cc], bb = FIN ? ks[WUNET_GZ_FIN_C + cc] : k2[cc], d = FIN ? ks[2 * WUNET_GZ_FIN_C + cc] : k3[cc];
+                const float a = kA[e], bb = kB[e], d = kD[e];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[e][j] = (ok && 4 * l4 + j < Lt) ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;     // (row padding: no gradient)
             }
@@ -504,6 +534,18 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
         // ---- phase 1: every load of the iteration
         float za[8], zb[8], av[8], sv[8], zq[2][8];
         bool from_up[8];
+        // the group's BatchNorm scale / shift as four 16-byte loads where its eight channels lie in ONE source (always for the decimating
+        // kinds; for the concat when the upsampled half ends on a group boundary) - the arrays' rows are padded to 64 floats, values past
+        // the last channel are zeroed below - instead of sixteen one-float loads beside the 8 - 16 that carry data
+        const bool vec_c = KIND == 0 || UP_ONLY || (A.C0 & 7) == 0;
+        if (vec_c) {
+            const bool upg = KIND == 0 || UP_ONLY || c8 * 8 < A.C0;
+            const float* const ap = upg ? A.a0 + c8 * 8 : A.a1 + (c8 * 8 - A.C0);
+            const float* const sp = upg ? A.s0 + c8 * 8 : A.s1 + (c8 * 8 - A.C0);
+            const wunet_f4 a0 = wunet_ld4(ap), a1 = wunet_ld4(ap + 4), s0 = wunet_ld4(sp), s1 = wunet_ld4(sp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { av[e] = a0[e]; av[4 + e] = a1[e]; sv[e] = s0[e]; sv[4 + e] = s1[e]; }
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = c8 * 8 + e;
@@ -513,7 +555,6 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                 const float* zr = A.z0 + ((size_t)b * A.C0 + cc) * (size_t)(2 * A.L);
                 za[e] = zr[2 * p];
                 zb[e] = 0.0f;
-                av[e] = A.a0[cc]; sv[e] = A.s0[cc];
                 if (SKIP_DST) { zq[0][e] = zr[q0]; zq[1][e] = zr[q0 + qstep]; }
             } else {
                 const bool up = UP_ONLY || cc < A.C0;
@@ -522,8 +563,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void prep_h3_kernel(PrepH3Args A)
                 const float* zr = up ? A.z0 + ((size_t)b * A.C0 + cu) * Lh : A.z1 + ((size_t)b * A.C1 + cs) * A.L;
                 za[e] = zr[up ? i0 : p];
                 zb[e] = zr[up ? i1 : p];
-                av[e] = up ? A.a0[cu] : A.a1[cs];
-                sv[e] = up ? A.s0[cu] : A.s1[cs];
+                if (!vec_c) {
+                    av[e] = up ? A.a0[cu] : A.a1[cs];
+                    sv[e] = up ? A.s0[cu] : A.s1[cs];
+                }
             }
         }
         // ---- phase 2: activate, scale, split, store

@@ -32,7 +32,8 @@
 template <int TAPS, int M_REP, int NSEG, bool BF = false, bool EVOP = false, int BSUM = 0>
 __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A)
 {
-    static_assert(BSUM == 0 || (NSEG == 1 && !BF && !EVOP), "BSUM: a training data gradient on whole-row tiles");
+    static_assert(BSUM == 0 || (NSEG == 1 && !BF && !EVOP), "BSUM / UPT: a training data gradient on whole-row tiles");
+    static_assert(BSUM != 3 || TAPS == 5, "UPT: a decoder layer");
     constexpr int PAD = TAPS / 2;
     constexpr int TG = 5;                         // taps per stage
     constexpr int NTG = TAPS / TG;
@@ -394,6 +395,87 @@ __global__ __launch_bounds__(WUNET_THREADS, 2) void conv_h3d_kernel(ConvH3Args A
             }                                                                                                     \
         }                                                                                                         \
     }
+        if (BSUM == 3) {
+            // ---- UPT (ConvH3Args::uh_out): the rows through the x2 upsample are stored pulled back to the producer's resolution
+            // (per-row addresses below = one per-lane base + offsets that are the same in every lane, and the bases derive from values made
+            //  opaque here: otherwise everything that does not depend on the work item is hoisted out of the loop over the items and lives
+            //  through the K loop, whose registers are spoken for)
+            int qe = q, pe = ll0;
+            wunet_opaque(qe);
+            wunet_opaque(pe);
+            const int p0 = l0 + pe, Lh = L >> 1;
+            float uw0[4], uw1[4], wp1, wn0;         // ATen's weights of the lane's outputs p0 .. p0 + 3, l1 of output p0 - 1, l0 of output p0 + 4
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { int i0_, i1_; wunet_up_coord(p0 + j, Lh, A.bs_up_scale, i0_, i1_, uw0[j], uw1[j]); }
+            { int i0_, i1_; float t_; wunet_up_coord(p0 > 0 ? p0 - 1 : 0, Lh, A.bs_up_scale, i0_, i1_, t_, wp1); }
+            { int i0_, i1_; float t_; wunet_up_coord(p0 + 4 < L ? p0 + 4 : L - 1, Lh, A.bs_up_scale, i0_, i1_, wn0, t_); }
+            // (output 0 of a row reads source 0 with weight 1, not the pair (-1, 0): its term goes to the lane's own first input)
+            const float ca0 = p0 == 0 ? uw0[0] : uw1[0];
+            constexpr int NRW = M_REP * 16;
+            // [wave][row of the block][2]: the wave's first and last data-gradient value of the row.  Per-lane bases: the lane's own slot,
+            // the previous wave's last value, the next wave's first
+            float* const ex_own = red + (wave * NRW + qe * 4) * 2;
+            const float* const ex_prev = red + ((wave > 0 ? wave - 1 : 0) * NRW + qe * 4) * 2 + 1;
+            const float* const ex_next = red + ((wave < WUNET_WAVES - 1 ? wave + 1 : 0) * NRW + qe * 4) * 2;
+#pragma unroll
+            for (int mt = 0; mt < M_REP; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (i16 == 0) ex_own[(mt * 16 + r) * 2] = acc[mt][0][r] * inv12;
+                    if (i16 == 15) ex_own[(mt * 16 + r) * 2 + 1] = acc[mt][3][r] * inv12;
+                }
+            wunet_wait_lds_barrier();
+            const int rb0 = mt0 * 16 + qe * 4;      // the lane's first row of the block's first m-tile
+            float* const hp0 = A.uh_out + ((size_t)bo * A.bs_c0 + rb0) * Lh + (p0 >> 1);
+            float* const prow_e = outp + ((size_t)bo * A.Cout + rb0) * L + p0;
+            float* const spa = A.uh_spill + (size_t)rb0 * A.ntiles + tile;                 // [0]: owed to the next tile's first input
+            float* const spb = spa + (size_t)A.bs_c0 * A.ntiles;                            // [1]: owed to the previous tile's last input
+            const bool edge_lo = wave == 0 && i16 == 0, edge_hi = wave == WUNET_WAVES - 1 && i16 == 15;
+#pragma unroll
+            for (int mt = 0; mt < M_REP; ++mt) {
+                const int rb = rb0 + mt * 16;
+                const bool live = rb < A.Cout && bo < A.B, up = rb < A.bs_c0;
+                // two rows at a time: a lane makes two inputs per row, the lanes of a pair (i16, i16 ^ 1) four consecutive ones - the even lane
+                // stores 16 bytes of the first row, the odd lane 16 bytes of the second (8-byte stores measured 11 % slower than the plain epilogue)
+#pragma unroll
+                for (int rp = 0; rp < 4; rp += 2) {
+                    float ga[2], gb[2];
+                    wunet_f4 ov[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int ro = mt * 16 + rp + h;      // row offset from the lane's base: the same in every lane
+                        wunet_f4 o;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) o[nt] = acc[mt][nt][rp + h] * inv12;
+                        ov[h] = o;
+                        // the neighbours' values: output p0 - 1 (the previous lane's last) and p0 + 4 (the next lane's first); across waves from
+                        // LDS, across tiles nothing - that term travels through uh_spill
+                        float dp = wunet_row16_shr1(o[3]), dn = wunet_row16_shl1(o[0]);
+                        if (i16 == 0) dp = wave > 0 ? ex_prev[ro * 2] : 0.0f;
+                        if (i16 == 15) dn = wave < WUNET_WAVES - 1 ? ex_next[ro * 2] : 0.0f;
+                        // input i receives, in ascending output j: l1(2i-1) d[2i-1] + l1(2i) d[2i] + l0(2i+1) d[2i+1] + l0(2i+2) d[2i+2]
+                        float a_ = wp1 * dp;
+                        a_ = fmaf(ca0, o[0], a_); a_ = fmaf(uw0[1], o[1], a_); a_ = fmaf(uw0[2], o[2], a_);
+                        float b_ = uw1[1] * o[1];
+                        b_ = fmaf(uw1[2], o[2], b_); b_ = fmaf(uw0[3], o[3], b_); b_ = fmaf(wn0, dn, b_);
+                        ga[h] = a_; gb[h] = b_;
+                    }
+                    const bool odd = (i16 & 1) != 0;
+                    const float ra = wunet_lane_swap1(odd ? ga[0] : ga[1]), rb_ = wunet_lane_swap1(odd ? gb[0] : gb[1]);
+                    const int ro = mt * 16 + rp;
+                    if (live && up) {
+                        const wunet_f4 w = odd ? wunet_f4{ra, rb_, ga[1], gb[1]} : wunet_f4{ga[0], gb[0], ra, rb_};
+                        wunet_st4(odd ? hp0 + (size_t)(ro + 1) * Lh - 2 : hp0 + (size_t)ro * Lh, w);
+                        if (edge_lo) { spb[(size_t)ro * A.ntiles] = p0 == 0 ? 0.0f : uw0[0] * ov[0][0]; spb[(size_t)(ro + 1) * A.ntiles] = p0 == 0 ? 0.0f : uw0[0] * ov[1][0]; }
+                        if (edge_hi) { spa[(size_t)ro * A.ntiles] = uw1[3] * ov[0][3]; spa[(size_t)(ro + 1) * A.ntiles] = uw1[3] * ov[1][3]; }
+                    } else if (live && (!(WUNET_ABL & 4) || ov[0][0] == 123.456f)) {
+                        wunet_st4(prow_e + (size_t)ro * L, ov[0]);
+                        wunet_st4(prow_e + (size_t)(ro + 1) * L, ov[1]);
+                    }
+                    wunet_sched_fence();              // (one pair of rows at a time)
+                }
+            }
+        } else
         if (BSUM) {
             // ---- data gradient + the producers' BatchNorm-backward sums (ConvH3Args::bs_*).  Two phases: (A) the sums, from the accumulators
             // and the producers' z rows - loads only, a ring of D rows in flight (hipcc counts loads and stores in ONE counter and waits

@@ -93,6 +93,8 @@ struct LayerPlan {
     size_t h3f_wpk, h3d_wpk;      // half offsets inside the split weight packs
     // BatchNorm-backward sums out of the consumers' data-gradient epilogues (conv_h3d_kernel<.., BSUM>, ConvH3Args::bs_*)
     size_t cst;                   // [cout][4] {a, s, mean, rstd}: the layer's BatchNorm constants as one 16-byte row per channel (training forward)
+    int upt;                      // a decoder layer whose data gradient stores its upsampled rows at the producer's resolution (conv_h3d_kernel<.., 3>)
+    size_t dxh, usp;              // ... [B][c0][L/2] and the tile-edge terms [2][c0][tiles]
     int bsum;                     // THIS layer's sums come from its consumers' epilogues: no pass_a_kernel, g_z from the data gradients
     int bs_kind;                  // this layer's own data gradient takes sums for (some of) its producers: 1 decoder form, 2 encoder form
     size_t bsp;                   // ... and writes them here: [cin][tiles][4]
@@ -148,7 +150,8 @@ int launch_split(const float* x, wunet_half* hi, wunet_half* lo, const float* sc
 struct ConvH3OpOut { wunet_half* h; wunet_half* l; const float* wl1; const float* xmax; float* xsc; int C8; };
 // (bs: training backward, the data gradient also takes the BatchNorm-backward sums of the layers that produced its rows - ConvH3Args::bs_*,
 //  conv_h3d_kernel<.., BSUM = kind>; a producer with z == nullptr keeps pass_a_kernel)
-struct ConvH3Bsum { int kind; const float* z[2]; const float* cst[2]; int C[2]; int c0; float up_scale; float* part; };
+struct ConvH3Bsum { int kind; const float* z[2]; const float* cst[2]; int C[2]; int c0; float up_scale; float* part;
+                    float* uh_out; float* uh_spill; };     // kind 3 (UPT): the rows < c0 stored pulled back through the upsample (ConvH3Args::uh_*)
 int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* xh, const wunet_half* xl, const wunet_half* wh,
                    const wunet_half* wl, const float* bias, const float* sc, const float* sc2, float* out, float* stats, int B, int rows,
                    int kch, int nch, int L, hipStream_t st, const void* zpad, const float* ev_a = nullptr, const float* ev_s = nullptr,

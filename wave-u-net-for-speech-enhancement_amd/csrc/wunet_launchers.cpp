@@ -136,18 +136,22 @@ int launch_conv_h3(int taps, int mrep, int mtiles_p, int sps, const wunet_half* 
     a.trace = g_h3_trace;
     if (op && (ksplit != 1 || nseg != 1 || !ev_a || !xrows)) return fail(WUNET_E_ARG, "conv_h3d EVOP needs an un-split whole-row eval launch");
     if (bs) {
-        if (ksplit != 1 || nseg != 1 || bf || op || bias || stats || xrows || (rows & 3) || (bs->c0 & 3) || !bs->part || (bs->kind != 1 && bs->kind != 2) ||
-            (bs->kind == 1) != (taps == 5))
-            return fail(WUNET_E_ARG, "conv_h3d BSUM needs an un-split whole-row data gradient with rows in groups of four");
+        const bool upt = bs->kind == 3;
+        if (ksplit != 1 || nseg != 1 || bf || op || bias || stats || xrows || (rows & 3) || (bs->c0 & 3) || bs->kind < 1 || bs->kind > 3 ||
+            (bs->kind != 2) != (taps == 5) || (upt ? (!bs->uh_out || !bs->uh_spill || bs->c0 > rows) : !bs->part))
+            return fail(WUNET_E_ARG, "conv_h3d BSUM / UPT needs an un-split whole-row data gradient with rows in groups of four");
         for (int k = 0; k < 2; ++k) { a.bs_z[k] = bs->z[k]; a.bs_cst[k] = bs->cst[k]; a.bs_C[k] = bs->C[k]; }
-        a.bs_c0 = bs->kind == 1 ? bs->c0 : rows; a.bs_up_scale = bs->up_scale; a.bs_part = bs->part;
+        a.bs_c0 = bs->kind == 2 ? rows : bs->c0; a.bs_up_scale = bs->up_scale; a.bs_part = bs->part;
+        a.uh_out = bs->uh_out; a.uh_spill = bs->uh_spill;
     }
     // conv_h3d_kernel: x tile and W sub-tile by LDS-DMA, buffers re-filled under the MFMAs, persistent blocks (two per CU)
-    snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" : bs ? "conv_h3d_kernel<%d, %d, %d, bsum>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
+    snprintf(pname, sizeof pname, bf ? "conv_h3d_kernel<%d, %d, %d, bf16>" : op ? "conv_h3d_kernel<%d, %d, %d, evop>" :
+             (bs && bs->kind == 3) ? "conv_h3d_kernel<%d, %d, %d, upt>" : bs ? "conv_h3d_kernel<%d, %d, %d, bsum>" : "conv_h3d_kernel<%d, %d, %d>", taps, mrep, nseg);
     // (BSUM: + the producers' z tiles the epilogue reads - 2 bytes per value through the upsample, 4 for a skip or decimated row)
     double bs_bytes = 0.0;
     if (bs && bs->kind == 1) bs_bytes = posn * ((bs->z[0] ? 2.0 * bs->c0 : 0.0) + (bs->z[1] ? 4.0 * (rows - bs->c0) : 0.0));
     if (bs && bs->kind == 2 && bs->z[0]) bs_bytes = posn * 4.0 * rows;
+    if (bs && bs->kind == 3) bs_bytes = -2.0 * posn * bs->c0;          // (UPT: the upsampled rows leave at half the length)
     prof_begin(st, pname, 2.0 * posn * rows * kch * taps, (bf ? 2.0 * posn * kch + 4.0 * posn * rows : 4.0 * posn * (rows + kch)) + (op ? 2.0 * posn * rows : 0.0) + bs_bytes);
     // (eval: BatchNorm scale / shift beside the bias in the block's table of per-row constants unless that costs the second block of a CU)
     a.epi_eval = (xrows && nseg == 1 && 2 * h3d_smem(nseg, mrep, bf, mtiles_p, 1) <= 160u * 1024u) ? 1 : 0;

@@ -600,6 +600,22 @@ void layout_workspace(wunet_ctx* c)
             if (q.bs_kind) { q.bsp = off; off += align64((size_t)q.cin * (((size_t)B * q.L + 255) / 256) * 4); }
         }
     }
+    // ---- UPT: a decoder layer's data gradient stores the rows of the upsampled half of its input pulled back through the upsample
+    // (conv_h3d_kernel<.., 3>, ConvH3Args::uh_*): un-split whole-row tiles, the producer on the split kernels.  WUNET_UPT=0: off (A/B switch).
+    {
+        const bool upt_off = getenv("WUNET_UPT") != nullptr && atoi(getenv("WUNET_UPT")) == 0;      // (read when a context is planned)
+        for (int i = 0; i < c->NL; ++i) { c->ly[i].upt = 0; c->ly[i].dxh = c->ly[i].usp = 0; }
+        for (int i = c->n + 1; i < c->NL && !upt_off; ++i) {
+            LayerPlan& q = c->ly[i];
+            const LayerPlan& p = c->ly[q.src0];
+            if (q.kind != LK_UPCAT || !q.h3d || q.bs_kind || q.L < 256 || q.d.ksplit != 1 || (q.c0 & 3) || (q.cin & 3) || q.c0 != p.cout || c->bf || c->padded ||
+                !p.h3d || p.L < 128 || !up_pairs_regular(q.L / 2))
+                continue;
+            q.upt = 1;
+            q.dxh = off; off += align64((size_t)B * q.c0 * (q.L / 2));
+            q.usp = off; off += align64((size_t)2 * q.c0 * (((size_t)B * q.L + 255) / 256));
+        }
+    }
     c->h3_wb_halfs = wbh;
     c->h3_wb_hi = off; off += align64((wbh + 1) / 2);
     c->h3_wb_lo = off; off += align64((wbh + 1) / 2);
