@@ -19,7 +19,9 @@ for src, dst in () if pmc_only else (("bench.json", "bench.json"), ("bench_bf16.
                  ("fwd_kernel_stats.csv", "forward_kernel_stats.csv"), ("host_phases.txt", "host_phases.txt"), ("next_rows_bench.txt", "next_rows_bench.txt"),
                  ("conv_ablation.txt", "conv_ablation.txt"), ("dma_issue_microbench.txt", "dma_issue_microbench.txt"),
                  ("h3u_sweep.txt", "h3u_threshold_sweep.txt"), ("h3u_ablation.txt", "h3u_ablation.txt"), ("h3u_stage_timeline.txt", "h3u_stage_timeline.txt"),
-                 ("round4_vs_round5_same_box.txt", "round4_vs_round5_same_box.txt"), ("evop_ab.txt", "evop_eval_ab.txt"), ("git_state.txt", "git_state.txt"), ("gpu_tests.txt", "gpu_tests.txt")):
+                 ("round4_vs_round5_same_box.txt", "round4_vs_round5_same_box.txt"), ("prev_vs_cur_same_box.txt", "previous_round_vs_this_same_box.txt"),
+                 ("upt_ab.txt", "upt_ab_same_box.txt"), ("wgrad_xcd_ab.txt", "wgrad_xcd_ab_same_box.txt"),
+                 ("evop_ab.txt", "evop_eval_ab.txt"), ("git_state.txt", "git_state.txt"), ("gpu_tests.txt", "gpu_tests.txt")):
     if not os.path.exists(os.path.join(F, src)):
         continue
     stamp = os.path.join(F, "git_state.txt")        # (gpurun merges into gpurun_out/ without deleting: leftovers of an earlier round are older than this run's stamp)
@@ -41,7 +43,9 @@ def lib_name(k):
     base, args = k.split("<", 1)
     a = [t.strip() for t in args.rstrip(">").split(",")]
     if base == "conv_h3d_kernel":
-        return "%s<%s, %s, %s%s>" % (base, a[0], a[1], a[2], ", bf16" if len(a) > 3 and a[3] == "true" else ", evop" if len(a) > 4 and a[4] == "true" else "")
+        mode = a[5] if len(a) > 5 else "0"           # (BSUM template argument: 1 / 2 = BatchNorm-backward sums in the epilogue, 3 = UPT)
+        return "%s<%s, %s, %s%s>" % (base, a[0], a[1], a[2], ", bf16" if len(a) > 3 and a[3] == "true" else ", evop" if len(a) > 4 and a[4] == "true" else
+                                     ", upt" if mode == "3" else ", bsum" if mode in ("1", "2") else "")
     if base == "conv_h3u_kernel":
         return "%s<%s>" % (base, a[0])
     if base == "wgrad_h3d_kernel":

@@ -81,11 +81,16 @@ cd $R
 timeout 300 python tools/next_rows_bench.py 2>/dev/null | grep -v amdgpu > $O/next_rows_bench.txt       # f1 / f3 / f4 of SURVEY.md section 8(f)
 # round 5: conv_h3u_kernel (eval decoder levels) - threshold sweep, ablation (tools/h3u_ablation.sh build first, in the container), stage timeline
 # (tools/build_h3u_trace.sh first); the previous round's library against this one on this box (tools/_lib_round4.so)
+if [ -n "$H3U_SET" ]; then       # (round 5's own studies of conv_h3u_kernel / EVOP: H3U_SET=1 repeats them)
 { echo "conv_h3u_kernel from different minimum levels, WUNET_H3U=<eval min L>,<train min L> (0: prep_h3_kernel + conv_h3d_kernel); eval forward and training step, batch 64, one box, first and last arm of each group the same (tools/h3u_ab.sh)"; EVAL_ARMS="0,0 2048,0 1024,0 512,0 256,0 0,0" TRAIN_ARMS="512,0 512,4096 512,2048 512,1024 512,512 512,0" timeout 500 bash tools/h3u_ab.sh; } > $O/h3u_sweep.txt 2>&1
 ls tools/_lib_u64.so > /dev/null 2>&1 && H3U=8192,0 timeout 300 bash tools/h3u_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/h3u_ablation.txt $O/h3u_ablation.txt
 [ -f tools/_lib_trace.so ] && timeout 120 python tools/h3u_trace.py 2>/dev/null | grep -v amdgpu > $O/h3u_stage_timeline.txt
-[ -f tools/_lib_round4.so ] && timeout 400 bash tools/round_vs_round.sh > $O/round4_vs_round5_same_box.txt 2>&1
-{ for rep in 1 2; do for v in "" 1; do if [ -z "$v" ]; then unset WUNET_NO_EVOP; else export WUNET_NO_EVOP=1; fi
+fi
+# the previous round's library (tools/_lib_round5.so) against this round's on this box; this round's switchable changes, each against its off arm
+[ -f tools/_lib_${PREV:-round5}.so ] && timeout 500 bash tools/round_vs_round.sh > $O/prev_vs_cur_same_box.txt 2>&1
+timeout 300 bash tools/upt_ab.sh > $O/upt_ab.txt 2>&1
+timeout 300 bash tools/env_ab.sh WUNET_WGRAD_XCD 0 > $O/wgrad_xcd_ab.txt 2>&1
+[ -n "$H3U_SET" ] && { for rep in 1 2; do for v in "" 1; do if [ -z "$v" ]; then unset WUNET_NO_EVOP; else export WUNET_NO_EVOP=1; fi
     python bench.py --mode forward --no-cpu-baseline --no-extras --no-roofline --steps 50 --warmup 10 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('WUNET_NO_EVOP=$v eval forward ms %.4f median %.4f' % (j['ms_per_step'], j['ms_per_step_median']))"; done; done; unset WUNET_NO_EVOP; } > $O/evop_ab.txt 2>&1
 ls tools/_lib_abl2.so > /dev/null 2>&1 && timeout 300 bash tools/conv_ablation.sh run > /dev/null 2>&1 && cp gpurun_out/conv_ablation.txt $O/conv_ablation.txt
 [ -x tools/microbench/_dma_issue ] && timeout 60 tools/microbench/_dma_issue > $O/dma_issue_microbench.txt

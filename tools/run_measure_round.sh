@@ -6,7 +6,7 @@
 # GPU box and collects the summaries into profiles/.
 set -e
 cd "$(dirname "$0")/.."
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 PKG=wave-u-net-for-speech-enhancement_amd
 if [ -n "$(git status --porcelain -- $PKG/csrc include bench.py tools/measure_round.sh tools/collect_round.py)" ]; then
     echo "refused: uncommitted changes under csrc/ include/ bench.py or the measurement tools:" >&2
