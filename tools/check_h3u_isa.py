@@ -1,6 +1,7 @@
 """conv_h3u_kernel's loader waves issue their prefetch loads from inline asm and order their use with hand-placed s_waitcnt (wunet_h3u.h):
 hipcc neither counts those loads nor protects their destination registers.  This checks, in the ISA hipcc generated for THIS build, the one
-thing the scheme depends on: between a prefetch load and the wait that covers it (the SECOND stage barrier `s_waitcnt vmcnt(10) lgkmcnt(0)`
+thing the scheme depends on: between a prefetch load and the wait that covers it (the SECOND stage barrier `s_waitcnt vmcnt(10) lgkmcnt(0)` -
+or `vmcnt(18)` behind a conversion that copied the operand to HBM: its 8 counted stores are younger than the loads as well -
 after it - a stage's barrier lets only the 10 loads issued in that stage stay outstanding, so the loads of the stage before have landed; they
 are consumed in the stage that follows) NO instruction reads or writes the load's destination registers - no compiler-inserted copy, no re-use
 as a temporary.  The steady loop is walked cyclically (three unrolled stages, rotating register sets).  (The per-item barrier of the
@@ -64,7 +65,8 @@ def check(name, lines):
         ins.append((("asm " + t) if in_asm else t, None))
     labels = {lab: i for i, (t, lab) in enumerate(ins) if lab}
     is_load = lambda t: t is not None and re.match(r"asm global_load_dword(x4)? v", t)
-    is_stage_barrier = lambda t: t is not None and re.match(r"asm s_waitcnt vmcnt\(10\) lgkmcnt\(0\)$", t)
+    # (vmcnt(18): the stage barrier behind a conversion that also copied the operand to HBM - 10 loads + WUNET_H3U_NST = 8 stores may stay in flight)
+    is_stage_barrier = lambda t: t is not None and re.match(r"asm s_waitcnt vmcnt\((10|18)\) lgkmcnt\(0\)$", t)
     is_full_wait = lambda t: t is not None and re.search(r"s_waitcnt (lgkmcnt\(0\) )?vmcnt\(0\)", t)
     loads = [i for i, (t, _) in enumerate(ins) if is_load(t)]
     nbar = sum(1 for t, _ in ins if is_stage_barrier(t))
@@ -215,6 +217,25 @@ def check(name, lines):
     return errs
 
 
+def check_store_counts(name, lines):
+    """The loaders' waits allow WUNET_H3U_NST = 8 stores per copying conversion to stay in flight: a conversion that issued FEWER would let
+    a wait return before the loads in front of it have landed.  In the ISA the loader side of a kernel holds 8 conversions (3 unrolled stages
+    x {row start, elsewhere} + 2 of the prologue); each must hold 8 16-byte and 2 two-byte stores of the copy - counted here over the kernel:
+    the two-byte stores only exist in the loaders (16 = 8 x 2), the 16-byte ones are 8 x 8 + the MFMA waves' epilogue rows."""
+    body = "\n".join(lines)
+    shorts = len(re.findall(r"global_store_short", body))
+    x4 = len(re.findall(r"global_store_dwordx4", body))
+    copy = "Lb1EE" in name                     # conv_h3u_kernel<M_REP, COPY = true>: the training instantiation
+    errs = []
+    if copy and shorts != 16:
+        errs.append(f"{name}: expected 16 two-byte stores of the loaders' operand copy (8 conversions x 2), found {shorts}")
+    if copy and x4 < 8 * 8:
+        errs.append(f"{name}: expected at least 64 16-byte stores of the loaders' operand copy, found {x4}")
+    if not copy and (shorts != 0 or "vmcnt(18)" in body):
+        errs.append(f"{name}: the eval instantiation holds operand-copy code ({shorts} two-byte stores)")
+    return errs
+
+
 def compile_isa():
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "h3u.s")
@@ -229,6 +250,7 @@ def main():
     for name, lines in kernels(asm):
         n += 1
         errs += check(name, lines)
+        errs += check_store_counts(name, lines)
     if n == 0:
         errs.append("no conv_h3u_kernel in the ISA")
     for e in errs[:20]:

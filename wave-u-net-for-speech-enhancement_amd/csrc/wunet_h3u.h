@@ -55,13 +55,23 @@ __device__ __forceinline__ void wunet_h3u_x_scale(const float* xb0, const float*
 // global loads the wave issued AFTER its last DMA piece: those are the prefetch of a tile two stages ahead and stay in flight across
 // the barrier (memory operations return in order: at most `younger` outstanding means everything older has completed).  Waiting for
 // vmcnt(0) here made every stage one full memory latency long (2.5 - 3 us per stage instead of ~1).
+// Training: the loaders also copy the operand to HBM (the weight gradient reads it) - WUNET_H3U_NST store instructions per converted tile,
+// issued BEHIND the stage's prefetch loads, so they are younger operations too: a barrier / wait that does not allow for them waits for the
+// prefetch loads instead (rounds 5: vmcnt(0) whenever the copy was on - the two-stage prefetch collapsed to one memory latency per
+// stage, decoder.11 172 us against 104 us without the copy).  The loaders keep count (wave-uniform: did the tile this wave converted last /
+// before last write its copy) and pick the wait that allows exactly the loads AND those stores.  WUNET_H3U_NST is a LOWER bound of the
+// stores a copying conversion issues (8 x 16 bytes + 2 x 2 bytes = 10 instructions; counting 8 waits for two of the oldest stores more than
+// needed, never for fewer operations than are in front of the loads - tools/check_h3u_isa.py counts the stores of every conversion in
+// the ISA of each build).
+#define WUNET_H3U_NST 8
 __device__ __forceinline__ void wunet_loader_barrier(int younger)
 {
 #ifdef WUNET_EMU
     (void)younger;
     emu::block_barrier();
 #else
-    if (younger >= 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (younger >= 10 + WUNET_H3U_NST) asm volatile("s_waitcnt vmcnt(18) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else if (younger >= 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else if (younger == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     wunet_sched_fence();
@@ -77,7 +87,8 @@ __device__ __forceinline__ void wunet_loader_stats_barrier(int younger)
     (void)younger;
     emu::block_barrier();
 #else
-    if (younger >= 10) asm volatile("s_waitcnt lgkmcnt(0) vmcnt(10)\n\ts_barrier" ::: "memory");
+    if (younger >= 10 + WUNET_H3U_NST) asm volatile("s_waitcnt lgkmcnt(0) vmcnt(18)\n\ts_barrier" ::: "memory");
+    else if (younger >= 10) asm volatile("s_waitcnt lgkmcnt(0) vmcnt(10)\n\ts_barrier" ::: "memory");
     else asm volatile("s_waitcnt lgkmcnt(0) vmcnt(0)\n\ts_barrier" ::: "memory");
     wunet_sched_fence();
 #endif
@@ -250,7 +261,7 @@ __device__ __forceinline__ int wunet_h3u_issue(const ConvH3uArgs& A, WunetH3uRaw
 // the conv's zero padding.  One tile in L / 256; every other tile runs the instantiation without a single select.
 // The BatchNorm coefficients in `coef` are PRE-MULTIPLIED by the operand's power-of-two scale (LeakyReLU and the interpolation commute with
 // it exactly).
-template <bool EDGE>
+template <bool EDGE, bool COPY>
 __device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
                                                     int lane, const WunetH3uCoord& K, const float* coef, unsigned long long* tr)
 {
@@ -290,7 +301,7 @@ __device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const 
         }
         return;
     }
-    const bool write_out = A.oxh != nullptr && T.mt0 == 0;
+    const bool write_out = COPY && T.mt0 == 0;      // (COPY: the training instantiation, ConvH3uArgs::oxh set)
     // BatchNorm scale / shift of the group's channels from the block's LDS table (a loaded from global memory here would be one more
     // memory round trip per stage - and its wait would drain the prefetched tiles with it)
     const int cc = c8 * 8;
@@ -374,11 +385,12 @@ __device__ __forceinline__ void wunet_h3u_convert_t(const ConvH3uArgs& A, const 
     }
 #undef WUNET_H3U_SUB
 }
+template <bool COPY>
 __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const WunetH3uRaw& R, const WunetH3uTile& T, wunet_half* xs, int cw,
                                                   int lane, const WunetH3uCoord& K, const float* coef, unsigned long long* tr = nullptr)
 {
-    if (wunet_uniform(T.l0) == 0) wunet_h3u_convert_t<true>(A, R, T, xs, cw, lane, K, coef, tr);
-    else wunet_h3u_convert_t<false>(A, R, T, xs, cw, lane, K, coef, tr);
+    if (wunet_uniform(T.l0) == 0) wunet_h3u_convert_t<true, COPY>(A, R, T, xs, cw, lane, K, coef, tr);
+    else wunet_h3u_convert_t<false, COPY>(A, R, T, xs, cw, lane, K, coef, tr);
 }
 
 // (-DWUNET_H3U_TRACE, tools/h3u_trace.py: lane 0 of MFMA wave 0 / loader wave 0 stamps its arrival at and its release from every stage
@@ -393,7 +405,11 @@ __device__ __forceinline__ void wunet_h3u_convert(const ConvH3uArgs& A, const Wu
 #define WUNET_H3U_STAMP(ROLE_, STAGE_, WHICH_)
 #endif
 
-template <int M_REP>
+static_assert(10 + WUNET_H3U_NST == 18, "the barrier spellings above");
+static_assert(20 + 2 * (2 * 4 + 1) + 2 * WUNET_H3U_NST <= 63, "vmcnt is a 6-bit field");
+// COPY: the training instantiation - the loaders also write the operand to A.oxh / A.oxl and count those stores in their waits; the eval
+// instantiation holds none of that code
+template <int M_REP, bool COPY = false>
 __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uArgs A)
 {
     constexpr int PAD = 2, TG = 5;
@@ -487,6 +503,10 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         // the older loads are the youngest ones outstanding, and the first use of a tile loaded two stages ago then waits for the loads
         // issued a moment before it - the prefetch collapses to one memory latency per stage.)
         WunetH3uRaw R0, R1, R2;
+        // did this wave's conversion of a tile issue the operand's copy (training; the first row block's loaders write it; a channel group
+        // beyond the operand writes nothing): of the tile converted last / before last (see WUNET_H3U_NST)
+        int wo_p = 0, wo_pp = 0;
+#define WUNET_H3U_COPIES(T_) ((COPY && (T_).mt0 == 0 && (T_).ch * 4 + cw < A.C8) ? 1 : 0)
         WunetH3uCursor c1, c3;                    // the tiles t + 1 (converted in stage t) and min(t + 3, T - 1) (loaded in stage t)
         int i3;                                   // c3's stage number
         WunetH3uCoord K;                          // of c1's item
@@ -509,14 +529,16 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
             if (t2.ch == 0) wunet_h3u_mini_src(A, t2.l0, lane, mi0, mi1);
             wunet_h3u_issue(A, R2, t2, cw, lane, mi0, mi1);
             wunet_vm_wait<0>();
-            wunet_h3u_convert(A, R0, t0, xs0, cw, lane, K, coef);
+            wunet_h3u_convert<COPY>(A, R0, t0, xs0, cw, lane, K, coef);
+            wo_p = WUNET_H3U_COPIES(t0);
         }
         // stage t (< T - 1): CUR_ holds the loads of tile t + 1, FREE_ (tile t's, converted a stage ago) takes those of tile t + 3; 10 loads
         // (tile t + 3's) are younger than the stage's last DMA piece at the next barrier
 #define WUNET_H3U_LOADER_STAGE(CUR_, FREE_)                                                                        \
     {                                                                                                              \
         WUNET_H3U_STAMP(1, t, 0)                                                                                   \
-        wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);                                                        \
+        if (COPY) wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10 + wo_p * WUNET_H3U_NST);                       \
+        else wunet_loader_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);         /* (eval: none of the bookkeeping) */     \
         WUNET_H3U_STAMP(1, t, 1)                                                                                   \
         wunet_h3u_advance(c1, S);                                                                                  \
         WUNET_H3U_TILE(c1, tn)                                                                                     \
@@ -526,11 +548,17 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         if (tnn.ch == 0) wunet_h3u_mini_src(A, tnn.l0, lane, mi0, mi1);                                            \
         wunet_h3u_issue(A, FREE_, tnn, cw, lane, mi0, mi1);                                                        \
         if (tn.ch == 0) wunet_h3u_coord(A, tn.l0, lane, K);                                                        \
-        /* tile t + 1's loads have landed: younger than them are the loads of tiles t + 2 and t + 3 (20) and the DMA pieces of two  \
-           stages (>= 2 M_REP + 1 per wave and stage); with the operand's copy to HBM in the queue as well (training) everything */  \
-        if (A.oxh) wunet_vm_wait<0>(); else wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                              \
-        wunet_h3u_convert(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, K, coef, WUNET_H3U_SUBPTR);          \
-        if (want_stats && tn.ch == 0) wunet_loader_stats_barrier((WUNET_H3U_ABL & 1) ? 0 : 10);           \
+        /* tile t + 1's loads have landed: younger than them are the loads of tiles t + 2 and t + 3 (20), the DMA pieces of two     \
+           stages (>= 2 M_REP + 1 per wave and stage) and the copies (training) of the two tiles converted since, WUNET_H3U_NST each */ \
+        if (COPY) {                                                                                                \
+            const int nwo_ = wunet_uniform(wo_p + wo_pp);                                                          \
+            if (nwo_ == 0) wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                                              \
+            else if (nwo_ == 1) wunet_vm_wait<20 + 2 * (2 * M_REP + 1) + WUNET_H3U_NST>();                         \
+            else wunet_vm_wait<20 + 2 * (2 * M_REP + 1) + 2 * WUNET_H3U_NST>();                                    \
+        } else wunet_vm_wait<20 + 2 * (2 * M_REP + 1)>();                                                          \
+        wunet_h3u_convert<COPY>(A, CUR_, tn, xs0 + ((t + 1) & 1) * XP * 8, cw, lane, K, coef, WUNET_H3U_SUBPTR);    \
+        if (COPY) { wo_pp = wo_p; wo_p = WUNET_H3U_COPIES(tn); }                                                   \
+        if (want_stats && tn.ch == 0) wunet_loader_stats_barrier((WUNET_H3U_ABL & 1) ? 0 : 10 + wo_p * WUNET_H3U_NST); \
         ++t;                                                                                                       \
     }
         int t = 0;
@@ -545,6 +573,7 @@ __global__ __launch_bounds__(2 * WUNET_THREADS, 1) void conv_h3u_kernel(ConvH3uA
         wunet_loader_barrier(0);
         if (want_stats) wunet_loader_stats_barrier(0);
 #undef WUNET_H3U_LOADER_STAGE
+#undef WUNET_H3U_COPIES
 #undef WUNET_H3U_DMA_W
 #undef WUNET_H3U_DMA_PIECE
 #undef WUNET_H3U_TILE
