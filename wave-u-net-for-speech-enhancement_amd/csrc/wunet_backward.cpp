@@ -201,16 +201,21 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                         const LayerPlan& dc = c->ly[2 * n - i];
                         hd.gd = ws + dc.dx; hd.Cg0 = dc.cin; hd.coff = dc.c0; hd.ge = ws + c->ly[i + 1].dx; hd.a = ws + l.a; hd.s = ws + l.s;
                     }
-                    if (fin_in_gz)
-                        WUNET_LAUNCH(gz_split_h3_kernel<true>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                                     (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
-                                     ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b, hd);
-                    else
-                        WUNET_LAUNCH(gz_split_h3_kernel<false>, dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z),
-                                     (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),
-                                     ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),
-                                     c->B, l.cout, c8, l.L, l.logL, c->bf, l.Lt, b, hd);
+                    // (the source of g is a compile-time mode of the kernel: every load of a thread is issued before its first use)
+                    const int gm = head_in_gz ? GZ_HEAD : enc_in_gz ? GZ_ENC : uph ? GZ_UPH : up_in_gz ? GZ_UP : GZ_G;
+#define WUNET_GZ_LAUNCH(FIN_, GM_, BF_)                                                                                                               \
+    WUNET_LAUNCH((gz_split_h3_kernel<FIN_, GM_, BF_>), dim3((unsigned)hb), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g), (const float*)(ws + l.z), \
+                 (const float*)(ws + l.k1), (const float*)(ws + l.k2), (const float*)(ws + l.k3), (const float*)(ws + c->bound_off),                 \
+                 ws + c->h3_slot + 8 + 4 * i, reinterpret_cast<wunet_half*>(ws + l.gzh), reinterpret_cast<wunet_half*>(ws + l.gzl),                  \
+                 c->B, l.cout, c8, l.L, l.logL, l.Lt, b, hd)
+#define WUNET_GZ_MODE(GM_)                                                                                                                            \
+    case GM_:                                                                                                                                         \
+        if (fin_in_gz) { if (c->bf) WUNET_GZ_LAUNCH(true, GM_, true); else WUNET_GZ_LAUNCH(true, GM_, false); }                                       \
+        else { if (c->bf) WUNET_GZ_LAUNCH(false, GM_, true); else WUNET_GZ_LAUNCH(false, GM_, false); }                                               \
+        break;
+                    switch (gm) { WUNET_GZ_MODE(GZ_G) WUNET_GZ_MODE(GZ_HEAD) WUNET_GZ_MODE(GZ_ENC) WUNET_GZ_MODE(GZ_UPH) WUNET_GZ_MODE(GZ_UP) }
+#undef WUNET_GZ_MODE
+#undef WUNET_GZ_LAUNCH
                     prof_end(st);
                 } else if (tiny)
                     WUNET_LAUNCH(gz_scalar_kernel, dim3((unsigned)((n4 * 4 + WUNET_THREADS - 1) / WUNET_THREADS) + 1), dim3(WUNET_THREADS), 0, st, (const float*)(ws + l.g),

@@ -298,13 +298,19 @@ struct GzHeadArgs {
 };
 #define WUNET_GZ_FIN_LOADS 1536   // (sweep 1152 / 2048 / 3100 / all: 5.41 / 5.42 / 5.46 / 5.50 ms per step - beyond the 512-sample level the prologue costs more than the launch)
 #define WUNET_GZ_FIN_C 512
-template <bool FIN>
+// GM (compile time): where g comes from.  Rounds 3 - 6 selected the mode by run-time tests of GzHeadArgs' pointers inside the unrolled loop over
+// the thread's eight channels: hipcc then cannot move a channel's loads across the branches - the ISA held `load z, branch, load g, s_waitcnt
+// vmcnt(0)` per channel, eight serialised memory round trips per thread at 197 VGPRs (two waves per SIMD) - and the pass ran at HALF the rate of
+// a kernel that moves the same bytes (tools/microbench/elem_passes.hip: 92.6 us against 46 us on decoder.10's geometry).  With the mode a
+// template parameter every load of the iteration is issued before the first value is used, as in prep_h3_kernel.
+enum { GZ_G = 0, GZ_HEAD = 1, GZ_ENC = 2, GZ_UPH = 3, GZ_UP = 4 };
+template <bool FIN, int GM, bool BFM>
 __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float* g, const float* z, const float* k1, const float* k2,
                                                                      const float* k3, const float* bound, float* sc, wunet_half* hi,
-                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int bf, int Lt,
+                                                                     wunet_half* lo, int B, int C, int C8, int L, int logL, int Lt,
                                                                      BnBwdArgs F, GzHeadArgs H)
 {
-    __shared__ float red[WUNET_THREADS];
+    __shared__ float red[WUNET_WAVES];
     __shared__ float ks[FIN ? 3 * WUNET_GZ_FIN_C : 3];
     float m = 0.0f;
     if (FIN) {
@@ -339,18 +345,21 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                 F.k1[c] = k1c; F.k2[c] = k2c; F.k3[c] = k3c; F.bound[c] = bc;
             }
         }
-    } else {
-        for (int c = threadIdx.x; c < C; c += WUNET_THREADS) m = fmaxf(m, bound[c]);
-    }
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int s = WUNET_THREADS / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) m = fmaxf(m, wunet_shfl_xor(m, x));
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
         __syncthreads();
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    } else {
+        // every WAVE takes the maximum over all channels itself (a maximum does not depend on the order: every wave of every block derives the
+        // same scale) - no LDS tree, no barrier in front of the data loads
+        for (int c = (int)(threadIdx.x & 63); c < C; c += 64) m = fmaxf(m, bound[c]);
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) m = fmaxf(m, wunet_shfl_xor(m, x));
     }
     float s = 1.0f, inv = 1.0f;
     {
-        const unsigned u = wunet_fbits(red[0]);
+        const unsigned u = wunet_fbits(m);
         if (u != 0 && u < 0x7f800000u) {
             int k = 9 - ((int)((u >> 23) & 0xffu) - 127);
             k = k > 100 ? 100 : (k < -100 ? -100 : k);
@@ -363,8 +372,9 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
     // would leave every store instruction of a wave 16-byte pieces at a 64-byte stride (measured on the operand passes and
     // here: partial-line scattered stores cost 1.3 % of the step in this kernel alone), so the wave's 4 KiB of hi and of lo
     // are turned in LDS: lane l then stores pieces l, 64+l, 128+l, 192+l - 1 KiB contiguous per instruction.  The output
-    // address of thread i is linear in i (piece 4*i + j), whatever the row boundaries.
-    __shared__ wunet_h8 tb[2][WUNET_THREADS * 4];
+    // address of thread i is linear in i (piece 4*i + j), whatever the row boundaries.  The turn is wave-private (a wave reads
+    // only what its own lanes wrote): no block barrier around it.
+    __shared__ wunet_h8 tb[BFM ? 1 : 2][WUNET_THREADS * 4];
     const int l4n = L >> 2;
     const size_t total = (size_t)B * C8 * l4n;
     const int lane = (int)(threadIdx.x & 63), wbase = (int)(threadIdx.x & ~63u);
@@ -374,74 +384,81 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
             const int l4 = (int)(i & (size_t)(l4n - 1));
             const size_t row = i >> (logL - 2);
             const int b = (int)(row / (size_t)C8), c8 = (int)(row - (size_t)b * C8);
-            wunet_f4 v[8];
+            const int c0_ = c8 * 8;
+            // ---- phase 1: every load of the iteration (clamped channels instead of branches around loads; values of channels >= C are zeroed below)
+            wunet_f4 zv[8], gv[8];
+            float2 e2[GM == GZ_ENC ? 8 : 1];
+            float whv[GM == GZ_HEAD ? 8 : 1];
             wunet_f4 gh4 = wunet_f4{0.f, 0.f, 0.f, 0.f};
-            if (H.gh) gh4 = wunet_ld4(H.gh + (size_t)b * L + 4 * l4);
+            if (GM == GZ_HEAD) gh4 = wunet_ld4(H.gh + (size_t)b * L + 4 * l4);
             WunetUpT U;
-            if (H.gu) wunet_upT_coords(4 * l4, Lt, H.up_scale, U);
-            // the eight channels' constants as 16-byte loads (k1 .. k3 and the BatchNorm scale / shift of the recompute modes: five arrays whose
-            // rows are padded to 64 floats - the loads past C stay inside them and their values are selected away): 10 load instructions per
-            // thread instead of 40 one-float loads beside the 16 that carry data
-            float kA[8], kB[8], kD[8], hA[8], hS[8];
-            {
-                const int c0_ = c8 * 8;
-                if (FIN) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { kA[e] = ks[c0_ + e]; kB[e] = ks[WUNET_GZ_FIN_C + c0_ + e]; kD[e] = ks[2 * WUNET_GZ_FIN_C + c0_ + e]; }
-                } else {
-                    const wunet_f4 a0 = wunet_ld4(k1 + c0_), a1 = wunet_ld4(k1 + c0_ + 4), b0 = wunet_ld4(k2 + c0_), b1 = wunet_ld4(k2 + c0_ + 4);
-                    const wunet_f4 d0 = wunet_ld4(k3 + c0_), d1 = wunet_ld4(k3 + c0_ + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { kA[e] = a0[e]; kA[4 + e] = a1[e]; kB[e] = b0[e]; kB[4 + e] = b1[e]; kD[e] = d0[e]; kD[4 + e] = d1[e]; }
-                }
-                if (H.a) {
-                    const wunet_f4 a0 = wunet_ld4(H.a + c0_), a1 = wunet_ld4(H.a + c0_ + 4), s0 = wunet_ld4(H.s + c0_), s1 = wunet_ld4(H.s + c0_ + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { hA[e] = a0[e]; hA[4 + e] = a1[e]; hS[e] = s0[e]; hS[4 + e] = s1[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hA[e] = hS[e] = 0.0f;
-                }
-            }
+            if (GM == GZ_UP) wunet_upT_coords(4 * l4, Lt, H.up_scale, U);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int c = c8 * 8 + e;
-                const bool ok = c < C;
-                const size_t o = ((size_t)b * C + (ok ? c : 0)) * L + 4 * l4;
-                const int cc = ok ? c : 0;
-                const wunet_f4 zv = wunet_ld4(z + o);
-                wunet_f4 gv;
+                const int cc = c0_ + e < C ? c0_ + e : C - 1;
+                const size_t o = ((size_t)b * C + cc) * L + 4 * l4;
+                zv[e] = wunet_ld4(z + o);
+                if (GM == GZ_G) gv[e] = wunet_ld4(g + o);
+                else if (GM == GZ_UPH) gv[e] = wunet_ld4(H.gq + o);        // (tile-edge values completed in place by pass_a_kernel<A_UPH>)
+                else if (GM == GZ_ENC) {
+                    gv[e] = wunet_ld4(H.gd + ((size_t)b * H.Cg0 + H.coff + cc) * L + 4 * l4);
+                    e2[e] = *reinterpret_cast<const float2*>(H.ge + ((size_t)b * C + cc) * (L >> 1) + 2 * l4);
+                } else if (GM == GZ_HEAD) whv[e] = H.wh[cc];
+            }
+            // the eight channels' constants as 16-byte loads (k1 .. k3 and the BatchNorm scale / shift of the recompute modes: five arrays whose
+            // rows are padded to 64 floats - the loads past C stay inside them and their values are selected away)
+            float kA[8], kB[8], kD[8], hA[8], hS[8];
+            if (FIN) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { kA[e] = ks[c0_ + e]; kB[e] = ks[WUNET_GZ_FIN_C + c0_ + e]; kD[e] = ks[2 * WUNET_GZ_FIN_C + c0_ + e]; }
+            } else {
+                const wunet_f4 a0 = wunet_ld4(k1 + c0_), a1 = wunet_ld4(k1 + c0_ + 4), b0 = wunet_ld4(k2 + c0_), b1 = wunet_ld4(k2 + c0_ + 4);
+                const wunet_f4 d0 = wunet_ld4(k3 + c0_), d1 = wunet_ld4(k3 + c0_ + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { kA[e] = a0[e]; kA[4 + e] = a1[e]; kB[e] = b0[e]; kB[4 + e] = b1[e]; kD[e] = d0[e]; kD[4 + e] = d1[e]; }
+            }
+            if (GM != GZ_G) {
+                const wunet_f4 a0 = wunet_ld4(H.a + c0_), a1 = wunet_ld4(H.a + c0_ + 4), s0 = wunet_ld4(H.s + c0_), s1 = wunet_ld4(H.s + c0_ + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { hA[e] = a0[e]; hA[4 + e] = a1[e]; hS[e] = s0[e]; hS[4 + e] = s1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) hA[e] = hS[e] = 0.0f;
+            }
+            // ---- phase 2: g (the recompute modes: pass_a_kernel's arithmetic in its order), g_z, the split
+            wunet_f4 v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool ok = c0_ + e < C;
                 const float ha = hA[e], hs = hS[e];
-                if (H.gh) {
-                    const float wh = H.wh[cc];
+                wunet_f4 gg = gv[e];
+                if (GM == GZ_HEAD) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float t = wh * gh4[j];
-                        if (!(ha * zv[j] + hs > 0.0f)) t *= WUNET_SLOPE;
-                        gv[j] = t;
+                        float t = whv[e] * gh4[j];
+                        if (!(ha * zv[e][j] + hs > 0.0f)) t *= WUNET_SLOPE;
+                        gg[j] = t;
                     }
-                } else if (H.gd) {
-                    const wunet_f4 d4 = wunet_ld4(H.gd + ((size_t)b * H.Cg0 + H.coff + cc) * L + 4 * l4);
-                    const float2 e2 = *reinterpret_cast<const float2*>(H.ge + ((size_t)b * C + cc) * (L >> 1) + 2 * l4);
-                    gv[0] = d4[0] + e2.x; gv[1] = d4[1]; gv[2] = d4[2] + e2.y; gv[3] = d4[3];
+                } else if (GM == GZ_ENC) {
+                    gg[0] = gv[e][0] + e2[e].x; gg[1] = gv[e][1]; gg[2] = gv[e][2] + e2[e].y; gg[3] = gv[e][3];
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (!(ha * zv[j] + hs > 0.0f)) gv[j] *= WUNET_SLOPE;
-                } else if (H.gq) {
+                        if (!(ha * zv[e][j] + hs > 0.0f)) gg[j] *= WUNET_SLOPE;
+                } else if (GM == GZ_UPH) {
                     // (a layer behind an upsample whose consumer's data gradient arrives at this resolution: pass_a_kernel<A_UPH>'s arithmetic)
-                    gv = wunet_ld4(H.gq + o);        // (tile-edge values completed in place by pass_a_kernel<A_UPH>)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (!(ha * zv[j] + hs > 0.0f)) gv[j] *= WUNET_SLOPE;
-                } else if (H.gu) {
-                    float gg[4];
-                    wunet_upT_row(H.gu + ((size_t)b * H.Cg0 + cc) * (size_t)(2 * L), 4 * l4, 2 * L, 2 * Lt, Lt, H.up_scale, U, gg);
+                        if (!(ha * zv[e][j] + hs > 0.0f)) gg[j] *= WUNET_SLOPE;
+                } else if (GM == GZ_UP) {
+                    float gu[4];
+                    const int cc = ok ? c0_ + e : C - 1;
+                    wunet_upT_row(H.gu + ((size_t)b * H.Cg0 + cc) * (size_t)(2 * L), 4 * l4, 2 * L, 2 * Lt, Lt, H.up_scale, U, gu);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) gv[j] = (ha * zv[j] + hs > 0.0f) ? gg[j] : gg[j] * WUNET_SLOPE;
-                } else gv = wunet_ld4(g + o);
+                    for (int j = 0; j < 4; ++j) gg[j] = (ha * zv[e][j] + hs > 0.0f) ? gu[j] : gu[j] * WUNET_SLOPE;
+                }
                 const float a = kA[e], bb = kB[e], d = kD[e];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[e][j] = (ok && 4 * l4 + j < Lt) ? s * (a * gv[j] + bb * zv[j] + d) : 0.0f;     // (row padding: no gradient)
+                for (int j = 0; j < 4; ++j) v[e][j] = (ok && 4 * l4 + j < Lt) ? s * (a * gg[j] + bb * zv[e][j] + d) : 0.0f;     // (row padding: no gradient)
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -449,12 +466,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     wunet_half x, y;
-                    wunet_split_rt(bf, v[e][j], x, y);
+                    wunet_split_rt(BFM ? 1 : 0, v[e][j], x, y);
                     wunet_put_half(h, e, x);
                     wunet_put_half(l, e, y);
                 }
                 tb[0][threadIdx.x * 4 + j] = h;
-                tb[1][threadIdx.x * 4 + j] = l;
+                if (!BFM) tb[1][threadIdx.x * 4 + j] = l;
             }
         }
         __syncthreads();
@@ -465,7 +482,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
             if (src < total) {
                 const size_t o = (4 * (base + wbase) + piece) * 8;
                 wunet_sth8(hi + o, tb[0][wbase * 4 + piece]);
-                if (!bf) wunet_sth8(lo + o, tb[1][wbase * 4 + piece]);
+                if (!BFM) wunet_sth8(lo + o, tb[1][wbase * 4 + piece]);
             }
         }
         __syncthreads();
