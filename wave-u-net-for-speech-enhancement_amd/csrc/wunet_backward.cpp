@@ -141,7 +141,9 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                 p.g1 = ws + c->spart_off; p.g1_splits = nx.d.ksplit; p.g1_stride = (size_t)c->B * nx.cin * nx.L;
             }
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else if (fuse && p.g1_splits > 1) WUNET_LAUNCH((pass_a_kernel<A_ENC, true, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_ENC, true>), ga, dim3(WUNET_THREADS), 0, st, p);
+            else if (p.g1_splits > 1) WUNET_LAUNCH((pass_a_kernel<A_ENC, false, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else WUNET_LAUNCH(pass_a_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
             prof_end(st);
         }

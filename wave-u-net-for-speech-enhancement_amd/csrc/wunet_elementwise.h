@@ -533,10 +533,49 @@ struct PassAArgs {
     const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
 };
 
-template <int MODE, bool FUSE = false>
+// The pass's closing reduction: two sums (three in HEAD mode) and two maxima over the block behind ONE barrier - butterflies inside each wave, the four
+// waves' values through LDS, added in block_sum2's order (the same bits).  Rounds 1 - 6 ran block_sum2, block_max2 (and a second block_sum2
+// in HEAD mode) one after the other: four to seven barriers at the end of blocks that are only 4 - 8 loop trips long.  Sums valid in every thread,
+// maxima too.  red: 5 * WUNET_WAVES doubles.
+__device__ __forceinline__ void block_reduce_pass_a(double& s1, double& s2, double& s3, bool want3, float& mg, float& mz, double* red)
+{
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        s1 += wunet_shfl_xor_d(s1, m);
+        s2 += wunet_shfl_xor_d(s2, m);
+        if (want3) s3 += wunet_shfl_xor_d(s3, m);
+        mg = fmaxf(mg, wunet_shfl_xor(mg, m));
+        mz = fmaxf(mz, wunet_shfl_xor(mz, m));
+    }
+    if ((tid & 63) == 0) {
+        const int w = tid >> 6;
+        red[w] = s1; red[WUNET_WAVES + w] = s2; red[2 * WUNET_WAVES + w] = s3;
+        red[3 * WUNET_WAVES + w] = (double)mg; red[4 * WUNET_WAVES + w] = (double)mz;        // (a float survives the round trip through a double)
+    }
+    __syncthreads();
+    s1 = (red[0] + red[1]) + (red[2] + red[3]);
+    s2 = (red[WUNET_WAVES] + red[WUNET_WAVES + 1]) + (red[WUNET_WAVES + 2] + red[WUNET_WAVES + 3]);
+    s3 = (red[2 * WUNET_WAVES] + red[2 * WUNET_WAVES + 1]) + (red[2 * WUNET_WAVES + 2] + red[2 * WUNET_WAVES + 3]);
+    mg = fmaxf(fmaxf((float)red[3 * WUNET_WAVES], (float)red[3 * WUNET_WAVES + 1]), fmaxf((float)red[3 * WUNET_WAVES + 2], (float)red[3 * WUNET_WAVES + 3]));
+    mz = fmaxf(fmaxf((float)red[4 * WUNET_WAVES], (float)red[4 * WUNET_WAVES + 1]), fmaxf((float)red[4 * WUNET_WAVES + 2], (float)red[4 * WUNET_WAVES + 3]));
+}
+
+// What one loop trip of pass A loads for its four samples (everything that comes from memory, nothing derived): two trips' loads are issued
+// before the first trip's values are used.
+template <int MODE>
+struct PassALoads {
+    wunet_f4 z, g;                       // z; HEAD: gh, UPH: dXh, ENC: dXdec
+    float e0, e1;                        // ENC: dXenc at l/2, l/2 + 1 (the split-K partials already added, in split order)
+    float d[MODE == A_UP ? 13 : 1];      // UP: dX at 2l - 4 .. 2l + 8
+    size_t zi; int b, l;
+};
+
+// G1S (ENC only, compile time): g1 points at split-K partials (A.g1_splits > 1) - as a run-time test inside the trip it kept the two trips' loads apart
+template <int MODE, bool FUSE = false, bool G1S = false>
 __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
 {
-    __shared__ double red[2 * WUNET_THREADS];
+    __shared__ double red[5 * WUNET_WAVES];
     // grid (C, splits), or (splits, C) with A.swap: consecutive blocks then walk consecutive pieces of ONE channel row
     const int c = A.swap ? blockIdx.y : blockIdx.x;
     const unsigned by = A.swap ? blockIdx.x : blockIdx.y, ny = A.swap ? gridDim.x : gridDim.y;
@@ -552,29 +591,29 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     size_t keep_i = 0;
     int keep_l = 0;
     bool have = false;
-    for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += WUNET_THREADS) {
+
+    // ---- the loads of one trip
+    auto load = [&](size_t q4, PassALoads<MODE>& t) {
         const size_t p = q4 << 2;
-        const int b = (int)(p >> A.logL), l = (int)(p & (size_t)(A.L - 1));
-        const size_t zi = ((size_t)b * A.C + c) * A.L + l;
-        const wunet_f4 z = wunet_ld4(A.z + zi);
-        float g[4];
-        if (MODE == A_HEAD) {
-            const wunet_f4 gh = wunet_ld4(A.g0 + (size_t)b * A.L + l);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                g[j] = wh * gh[j];
-                s3 += (double)(gh[j] * wunet_lrelu(a * z[j] + s));      // d(head weight of channel c)
-            }
-        } else if (MODE == A_UPH) {
-            float* const gq = const_cast<float*>(A.g0) + ((size_t)b * A.C + c) * A.L + l;
-            const wunet_f4 gp = wunet_ld4(gq);
-            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2]; g[3] = gp[3];
-            wunet_uph_edges(A.sp, A.C, A.ntiles, A.tpr, b, c, l, A.L, gq, g[0], g[3]);
-        } else if (MODE == A_ENC) {
-            const wunet_f4 gd = wunet_ld4(A.g0 + ((size_t)b * A.Cg0 + A.coff + c) * A.L + l);
+        t.b = (int)(p >> A.logL); t.l = (int)(p & (size_t)(A.L - 1));
+        const int b = t.b, l = t.l;
+        t.zi = ((size_t)b * A.C + c) * A.L + l;
+        t.z = wunet_ld4(A.z + t.zi);
+        t.e0 = t.e1 = 0.0f;
+        if (MODE == A_HEAD) t.g = wunet_ld4(A.g0 + (size_t)b * A.L + l);
+        else if (MODE == A_UPH) {
+            // the tile-edge terms (wunet_uph_edges) with the trip's other loads: clamped indices, the values of the lanes that are owed nothing
+            // are not used (as a conditional load inside the trip, every wave - each spans two tiles - waited for all its loads there)
+            t.g = wunet_ld4(A.g0 + t.zi);
+            const int tile = b * A.tpr + (l >> 7);
+            t.e0 = A.sp[(size_t)c * A.ntiles + (tile > 0 ? tile - 1 : 0)];
+            t.e1 = A.sp[((size_t)A.C + c) * A.ntiles + (tile + 1 < A.ntiles ? tile + 1 : tile)];
+        }
+        else if (MODE == A_ENC) {
+            t.g = wunet_ld4(A.g0 + ((size_t)b * A.Cg0 + A.coff + c) * A.L + l);
             const float* ge = A.g1 + ((size_t)b * A.C + c) * (A.L >> 1) + (l >> 1);
             float e0, e1;
-            if (A.g1_splits > 1) {                            // (four loads in flight, the order of split_sum_kernel's additions)
+            if (G1S) {                                        // (four loads in flight, the order of split_sum_kernel's additions)
                 e0 = e1 = 0.0f;
                 int k = 0;
                 for (; k + 4 <= A.g1_splits; k += 4) {
@@ -586,27 +625,59 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
                     e1 += t0.y; e1 += t1.y; e1 += t2.y; e1 += t3.y;
                 }
                 for (; k < A.g1_splits; ++k) {
-                    const float2 t = *reinterpret_cast<const float2*>(ge + (size_t)k * A.g1_stride);
-                    e0 += t.x; e1 += t.y;
+                    const float2 tt = *reinterpret_cast<const float2*>(ge + (size_t)k * A.g1_stride);
+                    e0 += tt.x; e1 += tt.y;
                 }
-            } else { e0 = ge[0]; e1 = ge[1]; }
-            g[0] = gd[0] + e0; g[1] = gd[1]; g[2] = gd[2] + e1; g[3] = gd[3];
+            } else { const float2 tt = *reinterpret_cast<const float2*>(ge); e0 = tt.x; e1 = tt.y; }
+            t.e0 = e0; t.e1 = e1;
         } else {
-            // transpose of ATen's upsample_linear1d: output j contributes l0 to input i0(j) and l1 to i1(j), with the
-            // fp32-computed coordinates; inputs l..l+3 can only be hit by outputs j in [2l-2, 2l+8], walked in
-            // ascending j like ATen's backward loop
-            const int Lo = 2 * A.L, Lot = 2 * A.Lt;               // row stride / samples that exist of the upsampled tensor
+            const int Lo = 2 * A.L;                               // row stride of the upsampled tensor
             const float* row = A.g0 + ((size_t)b * A.Cg0 + c) * Lo;
-            float d[12];
             const int j0 = 2 * l - 4;                         // 16-byte aligned
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const int jv = j0 + 4 * v;
                 const bool ok = jv >= 0 && jv < Lo;
-                const wunet_f4 t = wunet_sel4(ok, wunet_ld4(row + (ok ? jv : 0)));
-                d[4 * v] = t[0]; d[4 * v + 1] = t[1]; d[4 * v + 2] = t[2]; d[4 * v + 3] = t[3];
+                const wunet_f4 tt = wunet_sel4(ok, wunet_ld4(row + (ok ? jv : 0)));
+                t.d[(MODE == A_UP ? 4 * v : 0)] = tt[0]; t.d[(MODE == A_UP ? 4 * v + 1 : 0)] = tt[1];
+                t.d[(MODE == A_UP ? 4 * v + 2 : 0)] = tt[2]; t.d[(MODE == A_UP ? 4 * v + 3 : 0)] = tt[3];
             }
-            const float dlast = (j0 + 12 < Lo) ? row[j0 + 12] : 0.0f;
+            t.d[MODE == A_UP ? 12 : 0] = (j0 + 12 < Lo) ? row[j0 + 12] : 0.0f;
+            t.g = wunet_f4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- g of the trip's four samples, LeakyReLU', the sums
+    auto compute = [&](const PassALoads<MODE>& t) {
+        const int b = t.b, l = t.l;
+        const wunet_f4 z = t.z;
+        float g[4];
+        if (MODE == A_HEAD) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = wh * t.g[j];
+                s3 += (double)(t.g[j] * wunet_lrelu(a * z[j] + s));      // d(head weight of channel c)
+            }
+        } else if (MODE == A_UPH) {
+            float* const gq = const_cast<float*>(A.g0) + t.zi;
+            g[0] = t.g[0]; g[1] = t.g[1]; g[2] = t.g[2]; g[3] = t.g[3];
+            // wunet_uph_edges on the values loaded above: the first input of a tile is owed sp[0][c][tile - 1], the last sp[1][c][tile + 1]; row ends nothing
+            // (selects, not branches around the additions: hipcc sinks a load whose only use is conditional back into the branch)
+            const bool first = (l & 127) == 0 && l > 0, last = (l & 127) == 124 && l + 4 < A.L;
+            g[0] += first ? t.e0 : 0.0f;
+            g[3] += last ? t.e1 : 0.0f;
+            if (first) gq[0] = g[0];
+            if (last) gq[3] = g[3];
+        } else if (MODE == A_ENC) {
+            g[0] = t.g[0] + t.e0; g[1] = t.g[1]; g[2] = t.g[2] + t.e1; g[3] = t.g[3];
+        } else {
+            // transpose of ATen's upsample_linear1d: output j contributes l0 to input i0(j) and l1 to i1(j), with the
+            // fp32-computed coordinates; inputs l..l+3 can only be hit by outputs j in [2l-2, 2l+8], walked in
+            // ascending j like ATen's backward loop
+            const int Lot = 2 * A.Lt;                             // samples that exist of the upsampled tensor
+            const float* d = t.d;
+            const float dlast = t.d[MODE == A_UP ? 12 : 0];
+            const int j0 = 2 * l - 4;
             g[0] = g[1] = g[2] = g[3] = 0.0f;
             // interior threads: ATen's source pair of output j is ((j-1)>>1, +1) (checked against the exact coordinates), so
             // input i receives, in ascending j, l1(2i-1) d[2i-1] + l1(2i) d[2i] + l0(2i+1) d[2i+1] + l0(2i+2) d[2i+2]: four
@@ -624,16 +695,16 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             if (fast) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    g[m] += c1[2 * m] * d[2 * m + 3];
-                    g[m] += c1[2 * m + 1] * d[2 * m + 4];
-                    g[m] += c0[2 * m + 2] * d[2 * m + 5];
-                    g[m] += c0[2 * m + 3] * (m == 3 ? dlast : d[m == 3 ? 0 : 2 * m + 6]);
+                    g[m] += c1[2 * m] * d[MODE == A_UP ? 2 * m + 3 : 0];
+                    g[m] += c1[2 * m + 1] * d[MODE == A_UP ? 2 * m + 4 : 0];
+                    g[m] += c0[2 * m + 2] * d[MODE == A_UP ? 2 * m + 5 : 0];
+                    g[m] += c0[2 * m + 3] * (m == 3 ? dlast : d[MODE == A_UP ? (m == 3 ? 0 : 2 * m + 6) : 0]);
                 }
             } else
 #pragma unroll
             for (int k = 2; k <= 12; ++k) {                   // j = 2l-2 .. 2l+8
                 const int j = j0 + k;
-                const float dv = k < 12 ? d[k < 12 ? k : 0] : dlast;
+                const float dv = k < 12 ? d[MODE == A_UP ? (k < 12 ? k : 0) : 0] : dlast;
                 if (j >= 0 && j < Lot) {
                     int i0, i1; float l0, l1;
                     wunet_up_coord(j, A.Lt, A.up_scale, i0, i1, l0, l1);
@@ -659,10 +730,25 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             mg = fmaxf(mg, fabsf(gv));
             mz = fmaxf(mz, fabsf(zc));
         }
-        if (FUSE) { keep_g = go; keep_z = z; keep_i = zi; keep_l = l; have = true; }      // the thread's only iteration
-        else if (A.gpre) wunet_st4(A.gpre + zi, go);          // (nullptr: the consumer recomputes g - gz_split_h3_kernel's HEAD mode)
+        if (FUSE) { keep_g = go; keep_z = z; keep_i = t.zi; keep_l = l; have = true; }      // the thread's only trip
+        else if (A.gpre) wunet_st4(A.gpre + t.zi, go);          // (nullptr: the consumer recomputes g - gz_split_h3_kernel's recompute modes)
+    };
+
+    // two trips' loads in flight per thread (rounds 1 - 6: one trip's two 16-byte loads, waited for, used, then the next trip's); the trips are
+    // computed in the order of the one-trip loop (HEAD / UPH: every gradient bit-identical to the one-trip form on the GPU, tools/grad_dump.py;
+    // UP: hipcc contracts the transposed-upsample sums differently in this shape - 1e-7 relative).  Measured: pass A alone 44.6 -> 38.4 us on
+    // decoder.10's geometry back to back (tools/microbench/elem_passes.hip), 36 us per step of serial kernel time, nothing on the two-stream step -
+    // in the step the pass runs at what the memory system gives it behind a data gradient's 300 MB of write-backs
+    for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += 2 * WUNET_THREADS) {
+        PassALoads<MODE> t0, t1;
+        const bool two = !FUSE && q4 + WUNET_THREADS < end;
+        load(q4, t0);
+        if (!FUSE) load(two ? q4 + WUNET_THREADS : q4, t1);
+        compute(t0);
+        if (two) compute(t1);
     }
-    block_sum2(s1, s2, red);
+    const bool want_max = A.pmax != nullptr;
+    block_reduce_pass_a(s1, s2, s3, MODE == A_HEAD, mg, mz, red);
     if (FUSE) {
         // bn_finalize_bwd_kernel's arithmetic on the (float-rounded, as if through part[]) sums, then gz_materialize_kernel's
         const double t1 = (double)(float)s1, t2 = (double)(float)s2;
@@ -687,20 +773,12 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         float* pr = A.part + ((size_t)by * A.C + c) * 2;
         pr[0] = (float)s1;
         pr[1] = (float)s2;
-    }
-    if (A.pmax) {
-        block_max2(mg, mz, red);
-        if (threadIdx.x == 0) {
+        if (want_max) {
             float* pm = A.pmax + ((size_t)by * A.C + c) * 2;
             pm[0] = mg;
             pm[1] = mz;
         }
-    }
-    if (MODE == A_HEAD && A.hpart) {
-        double dummy = 0.0;
-        __syncthreads();
-        block_sum2(s3, dummy, red);
-        if (threadIdx.x == 0) A.hpart[(size_t)by * A.C + c] = (float)s3;
+        if (MODE == A_HEAD && A.hpart) A.hpart[(size_t)by * A.C + c] = (float)s3;
     }
 }
 
