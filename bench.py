@@ -507,6 +507,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    if os.environ.get("WUNET_STAMP") and not emu and args.mode == "train":
+        # measurement hook (csrc/wunet_backward.cpp, WUNET_STAMP): when the backward's two chains ran inside the LAST step above - device wall clock,
+        # 100 MHz - written to stderr, layer by layer in backward order: start of the data gradient, start of the weight gradient, relative to the first stamp
+        st_lib = ctypes.CDLL(importlib.import_module(PKG + "._lib").LIB_PATH)
+        buf = (ctypes.c_ulonglong * 128)()
+        if st_lib.wunet_debug_stamps(buf, 128) == 0:
+            t_first = min(v for v in buf if v)
+            nl = 2 * args.layers + 1
+            print("[stamps] layer: data-gradient chain reaches it at / weight gradient starts at (us after the first stamp), step_launch = %s" % ("graph" if use_graph else "eager"), file=sys.stderr)
+            for i in range(nl - 1, -1, -1):
+                a, b = buf[2 * i], buf[2 * i + 1]
+                print("[stamps] layer %2d  main %8.1f  side %8.1f  lag %8.1f" % (i, (a - t_first) / 100.0 if a else -1, (b - t_first) / 100.0 if b else -1, (b - a) / 100.0 if a and b else -1), file=sys.stderr)
+            print("[stamps] join: main chain done %8.1f, side chain done %8.1f" % ((buf[126] - t_first) / 100.0, (buf[127] - t_first) / 100.0), file=sys.stderr)
     # a second pass of the same K steps timed one by one with device events: the median is robust against a clock ramp or a
     # hiccup inside the short timed region above (which stays the headline, as the contract defines it)
     step_ms = []

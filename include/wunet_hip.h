@@ -133,6 +133,11 @@ int wunet_num_conv_layers(const wunet_ctx* ctx);
  * into buf and clears the records. */
 int wunet_profile_enable(int on);
 long long wunet_profile_collect(char* buf, size_t cap);
+/* Measurement hook (environment WUNET_STAMP=1, otherwise no launches): one-thread kernels write the device's 100 MHz wall clock beside the
+ * backward's launches - slot 2 i in front of layer i's data gradient on the caller's stream, slot 2 i + 1 in front of its weight gradient
+ * on the library's side stream, slots 126 / 127 where the two chains join.  They are captured into a step graph like any launch, so a graph
+ * REPLAY can be asked when its two chains ran without a tracer attached.  Copies up to 128 values of the last backward to `out`. */
+int wunet_debug_stamps(unsigned long long* out, int n);
 
 /* ---- data-parallel exchange: the flat fp32 gradient buffer summed over the GPUs of the job by RCCL.
  * Replaces what `torch.nn.DataParallel(model, device_ids=...)` does implicitly per step - replicate / scatter / gather and the

@@ -18,6 +18,7 @@ EXPORTS = [
     "wunet_adam_step", "wunet_set_h3", "wunet_op_conv1d_split", "wunet_op_conv1d_dgrad_split", "wunet_op_conv1d_wgrad_split",
     "wunet_backward_range_async", "wunet_backward_join", "wunet_debug_set_conv_trace", "wunet_crop_windows",
     "wunet_comm_unique_id", "wunet_comm_create", "wunet_comm_allreduce_sum", "wunet_comm_world", "wunet_comm_destroy",
+    "wunet_debug_stamps",
 ]
 
 _vp = ctypes.c_void_p
@@ -55,6 +56,8 @@ def declare(lib):
     lib.wunet_profile_enable.argtypes = [_i]
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
     lib.wunet_profile_collect.restype = ctypes.c_longlong
+    lib.wunet_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), _i]
+    lib.wunet_debug_stamps.restype = _i
     lib.wunet_crop_windows.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp]
     lib.wunet_comm_unique_id.argtypes = [_vp]
     lib.wunet_comm_create.argtypes = [_vp, _i, _i, ctypes.POINTER(_vp)]

@@ -7,6 +7,24 @@
 using namespace wunet_host;
 
 namespace {
+// ---- measurement hook (WUNET_STAMP=1; tools/stamp_probe.py): one-thread kernels that write the device's 100 MHz wall clock into a slot, enqueued
+// beside the backward's launches - in FRONT of a layer's data gradient on the caller's stream (slot 2 i), in FRONT of its weight gradient on
+// the side stream (slot 2 i + 1), at the join (slots 126, 127).  They are captured into a step graph like any launch, so a REPLAY can be asked
+// when its two chains really ran - a tracer changes how a graph is submitted.  Off: no launches, no allocation.
+#ifndef WUNET_EMU
+__global__ void stamp_kernel(unsigned long long* p) { *p = wall_clock64(); }
+unsigned long long* g_stamps = nullptr;
+bool stamps_on()
+{
+    static const bool on = getenv("WUNET_STAMP") != nullptr;
+    if (on && !g_stamps && (hipMalloc(&g_stamps, 128 * sizeof(unsigned long long)) != hipSuccess || hipMemset(g_stamps, 0, 128 * sizeof(unsigned long long)) != hipSuccess)) g_stamps = nullptr;
+    return on && g_stamps;
+}
+#define WUNET_STAMP(stream_, slot_) { if (stamps_on()) hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, stream_, g_stamps + (slot_)); }
+#else
+#define WUNET_STAMP(stream_, slot_) {}
+#endif
+
 // dx of an encoder-side layer i (1 <= i <= n: encoder 1 .. middle) has ONE reader, pass A of layer i - 1, the next kernel on the
 // stream: a split-K data gradient leaves its partials in the scratch and that pass adds them itself, in split order (same bits), instead
 // of a split_sum_kernel launch in between.  (A decoder layer's dx is read again much later - its skip half by the encoder side - and is
@@ -244,6 +262,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                 if (hipStreamWaitEvent(sd, side->ev_fork, 0) != hipSuccess)
                     return fail(WUNET_E_RUNTIME, "fork onto the weight-gradient stream failed");
             }
+            WUNET_STAMP(sd, 2 * i + 1)
             const float* xin = i == 0 ? noisy : ws + l.xin;
             const size_t nw = (size_t)l.cout * l.cin * l.taps;
             if (tiny) {
@@ -299,6 +318,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             return 0;
         };
         // ---- data gradient (not needed for the first layer): the same conv kernel on the flipped/transposed pack
+        WUNET_STAMP(st, 2 * i)
         if (i > 0 && l.h3d) {
             // fp16-split data gradient: scale g_z by a power of two into fp16's range, split, 3 MFMA passes, un-scale
             float* sc = ws + c->h3_slot + 8 + 4 * i;
@@ -364,6 +384,8 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
     // wunet_backward_join - except the range that ends the backward, which always joins: the next forward overwrites the
     // operands the side stream is still reading.
     if (sd != st && (join || layer_begin == 0)) {
+        WUNET_STAMP(st, 126)
+        WUNET_STAMP(sd, 127)
         if (hipEventRecord(side->ev_join, sd) != hipSuccess || hipStreamWaitEvent(st, side->ev_join, 0) != hipSuccess)
             return fail(WUNET_E_RUNTIME, "join of the weight-gradient stream failed");
     }
@@ -385,6 +407,17 @@ int wunet_backward_range_async(wunet_ctx* c, const float* noisy, const float* co
                                int layer_begin, int layer_end, void* stream)
 {
     return backward_range_impl(c, noisy, params, enhanced, grad_enhanced, workspace, grads, layer_begin, layer_end, stream, false);
+}
+
+// measurement hook: the stamps of the last backward (WUNET_STAMP=1), 128 device wall-clock values (100 MHz; 0 = slot not written)
+int wunet_debug_stamps(unsigned long long* out, int n)
+{
+#ifndef WUNET_EMU
+    if (!out || n < 0 || n > 128 || !g_stamps) return fail(WUNET_E_ARG, "no stamps (WUNET_STAMP unset, or no backward ran)");
+    return hipMemcpy(out, g_stamps, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? WUNET_OK : fail(WUNET_E_RUNTIME, "copy of the stamps failed");
+#else
+    (void)out; (void)n; return fail(WUNET_E_ARG, "no stamps in the emulator build");
+#endif
 }
 
 int wunet_backward_join(wunet_ctx* c, void* stream)
