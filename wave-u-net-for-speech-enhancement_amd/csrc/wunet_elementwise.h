@@ -1180,8 +1180,18 @@ static __global__ __launch_bounds__(WUNET_THREADS) void loss_partial_kernel(int 
 {
     __shared__ double red[2 * WUNET_THREADS];
     double s = 0.0, dummy = 0.0;
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS)
-        s += (double)loss_term(kind, enh[i] - clean[i]);
+    // four trips' loads in flight (a thread's 16 trips at batch 64 x 16384 were 16 dependent memory round trips: 10.4 us for 8 MB); the terms are
+    // added in the one-trip loop's order - the same bits
+    const size_t stride = (size_t)gridDim.x * WUNET_THREADS;
+    size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        float e[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e[u] = enh[i + u * stride]; c[u] = clean[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (double)loss_term(kind, e[u] - c[u]);
+    }
+    for (; i < n; i += stride) s += (double)loss_term(kind, enh[i] - clean[i]);
     block_sum2(s, dummy, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
