@@ -56,8 +56,9 @@ def declare(lib):
     lib.wunet_profile_enable.argtypes = [_i]
     lib.wunet_profile_collect.argtypes = [ctypes.c_char_p, _sz]
     lib.wunet_profile_collect.restype = ctypes.c_longlong
-    lib.wunet_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), _i]
-    lib.wunet_debug_stamps.restype = _i
+    if hasattr(lib, "wunet_debug_stamps"):       # (a measurement hook of round 6: saved libraries of earlier rounds - tools/round_vs_round.sh - do not have it)
+        lib.wunet_debug_stamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), _i]
+        lib.wunet_debug_stamps.restype = _i
     lib.wunet_crop_windows.argtypes = [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp, _vp, _vp]
     lib.wunet_comm_unique_id.argtypes = [_vp]
     lib.wunet_comm_create.argtypes = [_vp, _i, _i, ctypes.POINTER(_vp)]
