@@ -7,10 +7,11 @@
 using namespace wunet_host;
 
 namespace {
-// ---- measurement hook (WUNET_STAMP=1; tools/stamp_probe.py): one-thread kernels that write the device's 100 MHz wall clock into a slot, enqueued
+// ---- measurement hook (WUNET_STAMP=1; bench.py prints the slots): one-thread kernels that write the device's 100 MHz wall clock into a slot, enqueued
 // beside the backward's launches - in FRONT of a layer's data gradient on the caller's stream (slot 2 i), in FRONT of its weight gradient on
 // the side stream (slot 2 i + 1), at the join (slots 126, 127).  They are captured into a step graph like any launch, so a REPLAY can be asked
-// when its two chains really ran - a tracer changes how a graph is submitted.  Off: no launches, no allocation.
+// when its two chains really ran - a tracer changes how a graph is submitted.  Off: no launches, no allocation.  (The buffer is allocated by
+// the first backward that runs with the switch on: an eager warm-up step, never inside a capture.)
 #ifndef WUNET_EMU
 __global__ void stamp_kernel(unsigned long long* p) { *p = wall_clock64(); }
 unsigned long long* g_stamps = nullptr;
