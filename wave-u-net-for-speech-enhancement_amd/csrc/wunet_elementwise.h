@@ -401,7 +401,22 @@ static __global__ __launch_bounds__(WUNET_THREADS) void head_bwd_kernel(HeadBwdA
     const size_t beg = (size_t)blockIdx.x * per, end = beg + per < total ? beg + per : total;
     // pass 1: gh and the two channel-free sums
     double sb = 0.0, sin_ = 0.0;
-    for (size_t p = beg + threadIdx.x; p < end; p += WUNET_THREADS) {
+    // four trips' loads in flight (the store of a trip kept the next trip's loads behind it: eight serialised round trips per thread, 9.3 us for
+    // 16 MB); the trips are added in the one-trip loop's order - the same bits
+    size_t p = beg + threadIdx.x;
+    for (; p + 3 * WUNET_THREADS < end; p += 4 * WUNET_THREADS) {
+        float o[4], go[4], xi[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { o[u] = A.out[p + u * WUNET_THREADS]; go[u] = A.gout[p + u * WUNET_THREADS]; xi[u] = A.in[p + u * WUNET_THREADS]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float g = go[u] * (1.0f - o[u] * o[u]);
+            A.gh[p + u * WUNET_THREADS] = g;
+            sb += (double)g;
+            sin_ += (double)g * (double)xi[u];
+        }
+    }
+    for (; p < end; p += WUNET_THREADS) {
         const float o = A.out[p];
         const float g = A.gout[p] * (1.0f - o * o);
         A.gh[p] = g;
@@ -1209,8 +1224,16 @@ static __global__ __launch_bounds__(WUNET_THREADS) void loss_final_kernel(const 
 static __global__ __launch_bounds__(WUNET_THREADS) void loss_bwd_kernel(int kind, const float* clean, const float* enh, const float* gscale, size_t n, float* genh)
 {
     const float sc = gscale[0] / (float)n;
-    for (size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x; i < n; i += (size_t)gridDim.x * WUNET_THREADS)
-        genh[i] = sc * loss_dterm(kind, enh[i] - clean[i]);
+    const size_t stride = (size_t)gridDim.x * WUNET_THREADS;
+    size_t i = (size_t)blockIdx.x * WUNET_THREADS + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {             // (four trips' loads ahead of the first store)
+        float e[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { e[u] = enh[i + u * stride]; c[u] = clean[i + u * stride]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) genh[i + u * stride] = sc * loss_dterm(kind, e[u] - c[u]);
+    }
+    for (; i < n; i += stride) genh[i] = sc * loss_dterm(kind, enh[i] - clean[i]);
 }
 
 // ---------------------------------------------------------------------------- fused Adam
