@@ -108,24 +108,36 @@ struct BnFwdArgs {
     int training;
 };
 
+// What bn_finalize_core reads of channel c besides the sums.  Loaded at the TOP of the kernels that end in it (every thread loads the same
+// words: one broadcast line): as loads at their uses in thread 0's tail - between stores the compiler must assume they alias - they were five
+// dependent memory round trips behind the reduction, most of a 4.7 us kernel that sits on the layer-to-layer chain 18 times per step.
+struct BnFwdPre { float bias, gamma, beta, rmean, rvar; long long nbt; };
+__device__ __forceinline__ BnFwdPre bn_finalize_preload(const BnFwdArgs& A, int c)
+{
+    BnFwdPre P;
+    P.bias = A.bias[c]; P.gamma = A.gamma[c]; P.beta = A.beta[c]; P.rmean = A.running_mean[c]; P.rvar = A.running_var[c];
+    P.nbt = c == 0 ? *A.nbt : 0;
+    return P;
+}
 // thread 0 of the block owning channel c: turn (sum, sum of squares) of the bias-free conv into everything BN needs
-__device__ __forceinline__ void bn_finalize_core(const BnFwdArgs& A, int c, double s1, double s2)
+__device__ __forceinline__ void bn_finalize_core(const BnFwdArgs& A, int c, double s1, double s2, const BnFwdPre& P)
 {
     const double m0 = s1 / A.count;                   // mean of the bias-free conv
     double var = s2 / A.count - m0 * m0;              // biased variance (bias does not change it)
     var = var < 0.0 ? 0.0 : var;
-    const double mean = m0 + (double)A.bias[c];
+    const double mean = m0 + (double)P.bias;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-    const float a = A.gamma[c] * rstd;
+    const float a = P.gamma * rstd;
+    const float sh = P.beta - (float)mean * a;
     A.a[c] = a;
-    A.s[c] = A.beta[c] - (float)mean * a;
+    A.s[c] = sh;
     A.mean[c] = (float)mean;
     A.rstd[c] = rstd;
-    if (A.cst) { A.cst[4 * c] = a; A.cst[4 * c + 1] = A.s[c]; A.cst[4 * c + 2] = (float)mean; A.cst[4 * c + 3] = rstd; }
+    if (A.cst) { A.cst[4 * c] = a; A.cst[4 * c + 1] = sh; A.cst[4 * c + 2] = (float)mean; A.cst[4 * c + 3] = rstd; }
     const double unbiased = A.count > 1.0 ? var * A.count / (A.count - 1.0) : var;
-    A.running_mean[c] = (float)(0.9 * (double)A.running_mean[c] + 0.1 * mean);
-    A.running_var[c] = (float)(0.9 * (double)A.running_var[c] + 0.1 * unbiased);
-    if (c == 0) *A.nbt += 1;
+    A.running_mean[c] = (float)(0.9 * (double)P.rmean + 0.1 * mean);
+    A.running_var[c] = (float)(0.9 * (double)P.rvar + 0.1 * unbiased);
+    if (c == 0) *A.nbt = P.nbt + 1;
 }
 
 __device__ __forceinline__ void bn_eval_core(const BnFwdArgs& A, int c)
@@ -159,6 +171,7 @@ static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(B
         if (tid == 0) bn_eval_core(A, c);
         return;
     }
+    const BnFwdPre P = bn_finalize_preload(A, c);
     double s1 = 0.0, s2 = 0.0;
     const float2* st = reinterpret_cast<const float2*>(A.stats) + (size_t)c * A.rows;     // [C][rows][2]
     // (four loads in flight: a plain loop over the run-time row count waits for every load - up to 16 serialised round trips on
@@ -177,7 +190,7 @@ static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_fwd_kernel(B
         s2 += (double)v.y;
     }
     block_sum2(s1, s2, red);
-    if (tid == 0) bn_finalize_core(A, c, s1, s2);
+    if (tid == 0) bn_finalize_core(A, c, s1, s2, P);
 }
 
 // Split-K forward conv: sum the z-slices' partial outputs, add the bias, write z, and reduce the BatchNorm
@@ -253,6 +266,8 @@ static __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(Bn
         }
         return;
     }
+    BnFwdPre P{};
+    if (gridDim.y == 1) P = bn_finalize_preload(A, c);           // (this launch finishes BatchNorm itself)
     if ((L & 3) == 0) {
         // four samples per thread (16-byte loads and stores); every level of >= 4 samples
         const int total4 = total >> 2;
@@ -295,7 +310,7 @@ static __global__ __launch_bounds__(WUNET_THREADS) void conv_reduce_bn_kernel(Bn
             float* st = stats_rows + ((size_t)c * gridDim.y + blockIdx.y) * 2;
             st[0] = (float)s1;
             st[1] = (float)s2;
-        } else bn_finalize_core(A, c, s1, s2);
+        } else bn_finalize_core(A, c, s1, s2, P);
     }
 }
 
@@ -813,38 +828,34 @@ struct BnBwdArgs {
 
 static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArgs A)
 {
-    __shared__ double red[2 * WUNET_THREADS];
+    __shared__ double red[5 * WUNET_WAVES];
     const int c = blockIdx.x, tid = threadIdx.x;
-    double s1 = 0.0, s2 = 0.0;
+    // the channel's constants first, the sums' and the maxima's rows in ONE trip, one closing barrier (rounds 1 - 6: sums, two barriers, thread 0's
+    // loads of gamma / rstd / mean between its stores, then the maxima, two more barriers, the same loads again - a chain of dependent round
+    // trips in a kernel that is nothing else, ten times per step on the backward's chain).  Same sums in the same order: the same bits.
+    const float gam = A.gamma[c], rs = A.rstd[c], mu = A.mean[c];
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    float mg = 0.0f, mz = 0.0f;
     for (int r = tid; r < A.rows; r += WUNET_THREADS) {
-        const float* pr = A.part + ((size_t)r * A.C + c) * 2;
-        s1 += (double)pr[0];
-        s2 += (double)pr[1];
+        const float2 pr = *reinterpret_cast<const float2*>(A.part + ((size_t)r * A.C + c) * 2);
+        float2 pm = float2{0.0f, 0.0f};
+        if (A.pmax) pm = *reinterpret_cast<const float2*>(A.pmax + ((size_t)r * A.C + c) * 2);
+        s1 += (double)pr.x;
+        s2 += (double)pr.y;
+        mg = fmaxf(mg, pm.x);
+        mz = fmaxf(mz, pm.y);
     }
-    block_sum2(s1, s2, red);
+    block_reduce_pass_a(s1, s2, s3, false, mg, mz, red);
     if (tid == 0) {
+        const double m1 = s1 / A.count, m2 = s2 / A.count;
+        const double a = (double)gam * (double)rs;
         A.dgamma[c] = (float)s2;
         A.dbeta[c] = (float)s1;
         A.dbias[c] = 0.0f;
-        const double m1 = s1 / A.count, m2 = s2 / A.count;
-        const double a = (double)A.gamma[c] * (double)A.rstd[c];
         A.k1[c] = (float)a;
-        A.k2[c] = (float)(-a * m2 * (double)A.rstd[c]);
-        A.k3[c] = (float)(a * m2 * (double)A.rstd[c] * (double)A.mean[c] - a * m1);
-    }
-    if (A.pmax) {
-        float mg = 0.0f, mz = 0.0f;
-        for (int r = tid; r < A.rows; r += WUNET_THREADS) {
-            const float* pm = A.pmax + ((size_t)r * A.C + c) * 2;
-            mg = fmaxf(mg, pm[0]);
-            mz = fmaxf(mz, pm[1]);
-        }
-        block_max2(mg, mz, red);
-        if (tid == 0) {
-            const double m1 = s1 / A.count, m2 = s2 / A.count;
-            const double a = (double)A.gamma[c] * (double)A.rstd[c];
-            A.bound[c] = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)A.rstd[c]) * (double)mz + fabs(a * m1));
-        }
+        A.k2[c] = (float)(-a * m2 * (double)rs);
+        A.k3[c] = (float)(a * m2 * (double)rs * (double)mu - a * m1);
+        if (A.pmax) A.bound[c] = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)rs) * (double)mz + fabs(a * m1));
     }
 }
 
