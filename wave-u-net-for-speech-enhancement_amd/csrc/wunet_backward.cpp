@@ -81,10 +81,8 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         h.gh = ws + c->gh_off; h.part = ws + c->hpart_off; h.B = c->B; h.C = c->ci; h.T = c->T; h.logT = ilog2(c->T);
         WUNET_LAUNCH(head_bwd_kernel, dim3(c->head_blocks), dim3(WUNET_THREADS), 0, st, h);
         WUNET_CHECK_LAUNCH();
-        // d(weight of the input channel), d bias; the ci per-channel weight gradients come out of the last layer's pass A
-        WUNET_LAUNCH(rows_sum_kernel, dim3(2), dim3(WUNET_THREADS), 0, st,
-                     (const float*)(ws + c->hpart_off), c->head_blocks, 2, grads[4 * NL] + c->ci, 1, grads[4 * NL + 1]);
-        WUNET_CHECK_LAUNCH();
+        // (d(weight of the input channel), d bias and the ci per-channel head-weight gradients - sums of head_bwd_kernel's and of the last layer's
+        //  pass A's partial rows - are parameter gradients nothing on the chain reads: they are taken on the weight-gradient stream, below)
     }
 
     for (int i = layer_end - 1; i >= layer_begin; --i) {
@@ -132,9 +130,6 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             p.g0 = ws + c->gh_off; p.g1 = params[4 * NL]; p.hpart = ws + c->hpart2_off;
             WUNET_LAUNCH(pass_a_kernel<A_HEAD>, ga, dim3(WUNET_THREADS), 0, st, p);      // (the last layer has T >= 4 samples)
             prof_end(st);
-            WUNET_CHECK_LAUNCH();
-            WUNET_LAUNCH(rows_sum_kernel, dim3(c->ci), dim3(WUNET_THREADS), 0, st,
-                         (const float*)(ws + c->hpart2_off), l.a_split, c->ci, grads[4 * NL], c->ci, grads[4 * NL + 1]);
         } else if (i >= n && uph) {
             // the next decoder layer's data gradient arrived at THIS resolution (conv_h3d_kernel<.., 3>): elementwise; g is not stored -
             // gz_split_h3_kernel forms it again from the same two arrays (UPH mode)
@@ -264,6 +259,18 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     return fail(WUNET_E_RUNTIME, "fork onto the weight-gradient stream failed");
             }
             WUNET_STAMP(sd, 2 * i + 1)
+            if (i == NL - 1) {
+                // the head's parameter gradients (rounds 1 - 6: two 4.7 us launches between the kernels of the main chain, which never reads them):
+                // d(weight of the input channel), d bias from head_bwd_kernel's rows; the ci per-channel weight gradients from pass A's
+                WUNET_LAUNCH(rows_sum_kernel, dim3(2), dim3(WUNET_THREADS), 0, sd,
+                             (const float*)(ws + c->hpart_off), c->head_blocks, 2, grads[4 * NL] + c->ci, 1, grads[4 * NL + 1]);
+                WUNET_CHECK_LAUNCH();
+                if (!bsum) {
+                    WUNET_LAUNCH(rows_sum_kernel, dim3(c->ci), dim3(WUNET_THREADS), 0, sd,
+                                 (const float*)(ws + c->hpart2_off), l.a_split, c->ci, grads[4 * NL], c->ci, grads[4 * NL + 1]);
+                    WUNET_CHECK_LAUNCH();
+                }
+            }
             const float* xin = i == 0 ? noisy : ws + l.xin;
             const size_t nw = (size_t)l.cout * l.cin * l.taps;
             if (tiny) {

@@ -615,6 +615,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     const size_t beg = (size_t)by * per, end = beg + per < total4 ? beg + per : total4;
     const float a = A.a[c], s = A.s[c], mu = A.mean[c], rstd = A.rstd[c];
     const float wh = MODE == A_HEAD ? A.g1[c] : 0.0f;
+    const float gam = FUSE ? A.gamma[c] : 0.0f;          // (FUSE: needed behind the reduction - loaded here, not there)
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
     float mg = 0.0f, mz = 0.0f;
     wunet_f4 keep_g = wunet_f4{0.f, 0.f, 0.f, 0.f}, keep_z = keep_g;
@@ -783,7 +784,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         // bn_finalize_bwd_kernel's arithmetic on the (float-rounded, as if through part[]) sums, then gz_materialize_kernel's
         const double t1 = (double)(float)s1, t2 = (double)(float)s2;
         const double m1 = t1 / A.count, m2 = t2 / A.count;
-        const double ar = (double)A.gamma[c] * (double)rstd;
+        const double ar = (double)gam * (double)rstd;
         const float k1 = (float)ar, k2 = (float)(-ar * m2 * (double)rstd), k3 = (float)(ar * m2 * (double)rstd * (double)mu - ar * m1);
         if (threadIdx.x == 0) {
             A.dgamma[c] = (float)t2;
