@@ -655,9 +655,16 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
                     e0 += t0.x; e0 += t1.x; e0 += t2.x; e0 += t3.x;
                     e1 += t0.y; e1 += t1.y; e1 += t2.y; e1 += t3.y;
                 }
-                for (; k < A.g1_splits; ++k) {
-                    const float2 tt = *reinterpret_cast<const float2*>(ge + (size_t)k * A.g1_stride);
-                    e0 += tt.x; e1 += tt.y;
+                if (k < A.g1_splits) {
+                    // the one to three splits left over: loaded together (clamped indices), added in split order under selects (one at a time
+                    // they were up to three more dependent round trips per trip of a launch that is latency from end to end)
+                    const int last = A.g1_splits - 1;
+                    const float2 t0 = *reinterpret_cast<const float2*>(ge + (size_t)k * A.g1_stride);
+                    const float2 t1 = *reinterpret_cast<const float2*>(ge + (size_t)(k + 1 < last ? k + 1 : last) * A.g1_stride);
+                    const float2 t2 = *reinterpret_cast<const float2*>(ge + (size_t)(k + 2 < last ? k + 2 : last) * A.g1_stride);
+                    e0 += t0.x; e1 += t0.y;           // (selects, not branches: hipcc sinks a load whose only use is conditional into the branch)
+                    e0 += k + 1 <= last ? t1.x : 0.0f; e1 += k + 1 <= last ? t1.y : 0.0f;
+                    e0 += k + 2 <= last ? t2.x : 0.0f; e1 += k + 2 <= last ? t2.y : 0.0f;
                 }
             } else { const float2 tt = *reinterpret_cast<const float2*>(ge); e0 = tt.x; e1 = tt.y; }
             t.e0 = e0; t.e1 = e1;
