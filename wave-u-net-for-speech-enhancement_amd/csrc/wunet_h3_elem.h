@@ -317,6 +317,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
         for (int c = threadIdx.x; c < C; c += WUNET_THREADS) {
             double s1 = 0.0, s2 = 0.0;
             float mg = 0.0f, mz = 0.0f;
+            const float gam_ = F.gamma[c], rs_ = F.rstd[c], mu_ = F.mean[c];     // (with the rows' loads, not behind their sums: one round trip less in front of the data)
             for (int r0 = 0; r0 < F.rows; r0 += 8) {
                 float p1[8], p2[8], q1[8], q2[8];
 #pragma unroll
@@ -334,10 +335,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void gz_split_h3_kernel(const float*
                 }
             }
             const double m1 = s1 / F.count, m2 = s2 / F.count;
-            const double a = (double)F.gamma[c] * (double)F.rstd[c];
-            const float k1c = (float)a, k2c = (float)(-a * m2 * (double)F.rstd[c]);
-            const float k3c = (float)(a * m2 * (double)F.rstd[c] * (double)F.mean[c] - a * m1);
-            const float bc = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)F.rstd[c]) * (double)mz + fabs(a * m1));
+            const double a = (double)gam_ * (double)rs_;
+            const float k1c = (float)a, k2c = (float)(-a * m2 * (double)rs_);
+            const float k3c = (float)(a * m2 * (double)rs_ * (double)mu_ - a * m1);
+            const float bc = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)rs_) * (double)mz + fabs(a * m1));
             ks[c] = k1c; ks[WUNET_GZ_FIN_C + c] = k2c; ks[2 * WUNET_GZ_FIN_C + c] = k3c;
             m = fmaxf(m, bc);
             if (blockIdx.x == 0) {
