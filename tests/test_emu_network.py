@@ -473,3 +473,41 @@ def test_eval_encoder_conv_writes_the_next_operand(monkeypatch, n, ci, B, T, gri
     assert np.abs(new - ref).max() < 2e-6 and np.abs(new - old).max() < 1e-6
     assert not np.array_equal(new, old)             # (another scale, another rounding of the lo halves: really the other path)
     assert np.array_equal(new, again)
+
+
+@pytest.mark.parametrize("n,ci,B,T", [(2, 24, 2, 1024), (3, 24, 3, 2048), (2, 16, 5, 512), (2, 24, 2, 768), (3, 24, 1, 1536)])
+def test_first_layer_weight_gradient_from_the_gradient_assembly_sums(monkeypatch, n, ci, B, T):
+    """The first layer (Cin = 1, model/unet_basic.py:44-50): dW[c][k] = sum g_z[b,c,l] x[b,l+k-7] with g_z = k1 g + k2 z + k3 is three sums per tap that
+    need no BatchNorm constant; pass_a_kernel<.., E0> takes them while it forms g (which it then does not write), bn_finalize_bwd_kernel combines them - no
+    weight-gradient GEMM, no split reduce for that layer.  Against the float64 oracle and against the same step with the GEMM (WUNET_NO_E0=1)."""
+    import ctypes
+    from test_scale_robustness import errors, run_step
+    eng_mod = importlib.import_module(PKG_NAME + ".engine")
+    lib_mod = importlib.import_module(PKG_NAME + "._lib")
+    monkeypatch.setenv("WUNET_H3_NOSPLIT", "1")          # (small shapes: encoder.1's data gradient un-split, as at the BASELINE size)
+    sd = plan.golden_state(n, ci, 0)
+    noisy, clean = plan.golden_batch(B, T, 0)
+    ref = c_oracle.step({k: v.copy() for k, v in sd.items()}, noisy, clean, n, ci, True, "mse", precision="f64")
+    got = {}
+    for v in ("", "1"):
+        if v:
+            monkeypatch.setenv("WUNET_NO_E0", v)
+        else:
+            monkeypatch.delenv("WUNET_NO_E0", raising=False)
+        eng = eng_mod.Engine(lib=lib_mod.declare(emu_lib.lib()), host_memory=True, h3=2)
+        eng.lib.wunet_profile_enable(1)
+        out, grads = run_step(eng, sd, n, ci, noisy, clean)
+        buf = ctypes.create_string_buffer(1 << 16)
+        eng.lib.wunet_profile_collect(buf, len(buf))
+        eng.lib.wunet_profile_enable(0)
+        names = {ln.split("\t")[0]: int(ln.split("\t")[1]) for ln in buf.value.decode().strip().splitlines()}
+        got[v] = (out, grads, names)
+        oe, ge = errors(out, grads, ref)
+        assert oe < 2e-5 and ge < 3e-4, (v, oe, ge)
+    assert got[""][2].get("pass_a_kernel<ENC, e0>", 0) == 1 and "pass_a_kernel<ENC, e0>" not in got["1"][2]
+    k = "encoder.0.main.0.weight"
+    a, b = got[""][1][k], got["1"][1][k]
+    assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+    for kk, g in got[""][1].items():            # nothing else moves
+        if kk != k:
+            assert np.array_equal(g, got["1"][1][kk]), kk

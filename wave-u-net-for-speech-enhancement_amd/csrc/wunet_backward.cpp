@@ -107,6 +107,9 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         // a whole channel in one pass of one block (the levels of <= 16 samples at batch 64): BatchNorm-backward finalize and
         // g_z inside pass A - two launches of ~5 us (latency, not bandwidth) less per such level
         const bool fuse = !tiny && i < NL - 1 && !(i > 0 && l.h3d) && l.a_split == 1 && (size_t)c->B * l.L <= 4 * WUNET_THREADS;
+        // the first layer (Cin = 1, 15 taps): its weight gradient's sums are taken by this pass and finished by the finalize - no g written, no
+        // weight-gradient GEMM, no split reduce (the last 66 us of the backward, alone on the chip; WUNET_NO_E0=1 when the context is planned: A/B switch)
+        const bool e0 = c->e0 && gz_in_wgrad && !fuse && l.cin == 1 && l.taps == 15 && l.L >= 16 && !dx_stays_split(c, 1) && n >= 1;
         if (fuse) {
             p.gamma = params[4 * i + 2]; p.dgamma = grads[4 * i + 2]; p.dbeta = grads[4 * i + 3]; p.dbias = grads[4 * i + 1];
             p.k1 = ws + l.k1; p.k2 = ws + l.k2; p.k3 = ws + l.k3; p.count = (double)c->B * l.Lt;
@@ -121,8 +124,8 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
         const bool uph = !bsum && i >= n && i + 1 < NL && c->ly[i + 1].upt && l.h3d && !fuse && !tiny;
         if (!bsum) {   // algorithmic bytes of the gradient assembly (HBM-bound): z + the consumers' data gradients read, g written
             const double pe = (double)c->B * l.cout * l.L;
-            const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : "pass_a_kernel<ENC>";
-            prof_begin(st, uph ? "pass_a_kernel<UPH>" : nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : uph ? 8.0 : i >= n ? 16.0 : (enc_in_gz ? 10.0 : 14.0)) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
+            const char* nm = i == NL - 1 ? "pass_a_kernel<HEAD>" : i >= n ? "pass_a_kernel<UP>" : e0 ? "pass_a_kernel<ENC, e0>" : "pass_a_kernel<ENC>";
+            prof_begin(st, uph ? "pass_a_kernel<UPH>" : nm, 0.0, pe * (i == NL - 1 ? (head_in_gz ? 4.0 : 8.0) : uph ? 8.0 : i >= n ? 16.0 : ((enc_in_gz || e0) ? 10.0 : 14.0)) + (i == NL - 1 ? 4.0 * c->B * l.L : 0.0));
         }
         if (bsum) {
         } else if (i == NL - 1) {
@@ -154,7 +157,9 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             if (dx_stays_split(c, i + 1)) {
                 p.g1 = ws + c->spart_off; p.g1_splits = nx.d.ksplit; p.g1_stride = (size_t)c->B * nx.cin * nx.L;
             }
+            if (e0) { p.gpre = nullptr; p.x0 = noisy; p.e0rows = ws + c->e0part_off; }
             if (tiny) WUNET_LAUNCH(pass_a_scalar_kernel<A_ENC>, ga, dim3(WUNET_THREADS), 0, st, p);
+            else if (e0) WUNET_LAUNCH((pass_a_kernel<A_ENC, false, false, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse && p.g1_splits > 1) WUNET_LAUNCH((pass_a_kernel<A_ENC, true, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else if (fuse) WUNET_LAUNCH((pass_a_kernel<A_ENC, true>), ga, dim3(WUNET_THREADS), 0, st, p);
             else if (p.g1_splits > 1) WUNET_LAUNCH((pass_a_kernel<A_ENC, false, true>), ga, dim3(WUNET_THREADS), 0, st, p);
@@ -168,6 +173,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
             b.dgamma = grads[4 * i + 2]; b.dbeta = grads[4 * i + 3]; b.dbias = grads[4 * i + 1]; b.k1 = ws + l.k1; b.k2 = ws + l.k2; b.k3 = ws + l.k3;
             b.C = l.cout; b.count = (double)c->B * l.Lt;
             b.pmax = (i > 0 && l.h3d) ? ws + c->bmax_off : nullptr; b.bound = ws + c->bound_off;
+            if (e0) { b.e0rows = ws + c->e0part_off; b.dw0 = grads[0]; }
             // (short levels on the split kernels: the finalize runs in the prologue of gz_split_h3_kernel's blocks instead -
             //  WUNET_NO_BWDFIN_FUSE=1: A/B switch)
             const bool fin_in_gz = !bsum && i > 0 && l.h3d && l.a_split * l.cout <= WUNET_GZ_FIN_LOADS && l.cout <= WUNET_GZ_FIN_C;
@@ -271,6 +277,7 @@ int backward_range_impl(wunet_ctx* c, const float* noisy, const float* const* pa
                     WUNET_CHECK_LAUNCH();
                 }
             }
+            if (e0) return 0;                          // (finished by bn_finalize_bwd_kernel from pass A's sums)
             const float* xin = i == 0 ? noisy : ws + l.xin;
             const size_t nw = (size_t)l.cout * l.cin * l.taps;
             if (tiny) {

@@ -558,6 +558,10 @@ struct PassAArgs {
     int Lt;              // samples of a row that exist (<= L, the power-of-two row stride; PrepArgs::Lt): the padding gets no gradient
     const float* sp;     // UPH: the tile-edge terms [2][C][ntiles] (g0 = dXh [B][C][L])
     int ntiles, tpr;     // UPH: tiles of the consumer's data gradient, tiles per row (L / 128)
+    // E0 (the first layer, Cin = 1, 15 taps): its weight gradient dW[c][k] = sum g_z[b,c,l] x[b,l+k-7] with g_z = k1 g + k2 z + k3 is three sums per
+    // tap that need no BatchNorm constant - sum g x, sum z x, sum x over the positions that exist - taken by THIS pass, which reads z and forms g
+    // anyway; bn_finalize_bwd_kernel combines them.  x0: the input waveform [B][L] (zero beyond the samples that exist); e0rows [pieces][C][48].
+    const float* x0; float* e0rows;
     // FUSE (a whole channel in one pass of one block: B*L <= 1024): BatchNorm-backward finalize and g_z in the same launch -
     // gpre receives g_z = k1*g + k2*z + k3 directly, part is not written (bn_finalize_bwd_kernel + gz_materialize_kernel)
     const float* gamma; float* dgamma; float* dbeta; float* dbias; float* k1; float* k2; float* k3; double count;
@@ -593,19 +597,27 @@ __device__ __forceinline__ void block_reduce_pass_a(double& s1, double& s2, doub
 
 // What one loop trip of pass A loads for its four samples (everything that comes from memory, nothing derived): two trips' loads are issued
 // before the first trip's values are used.
-template <int MODE>
+template <int MODE, bool E0 = false>
 struct PassALoads {
     wunet_f4 z, g;                       // z; HEAD: gh, UPH: dXh, ENC: dXdec
     float e0, e1;                        // ENC: dXenc at l/2, l/2 + 1 (the split-K partials already added, in split order)
     float d[MODE == A_UP ? 13 : 1];      // UP: dX at 2l - 4 .. 2l + 8
+    wunet_f4 xw[E0 ? 5 : 1];             // E0: the input waveform at l - 8 .. l + 11
     size_t zi; int b, l;
 };
 
 // G1S (ENC only, compile time): g1 points at split-K partials (A.g1_splits > 1) - as a run-time test inside the trip it kept the two trips' loads apart
-template <int MODE, bool FUSE = false, bool G1S = false>
+template <int MODE, bool FUSE = false, bool G1S = false, bool E0 = false>
 __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
 {
+    static_assert(!E0 || (MODE == A_ENC && !FUSE && !G1S), "E0: the first layer's gradient assembly");
     __shared__ double red[5 * WUNET_WAVES];
+    __shared__ float e0x[E0 ? WUNET_WAVES * 48 : 1];
+    float w1[E0 ? 15 : 1], w2[E0 ? 15 : 1], w3[E0 ? 15 : 1];          // E0: sum g x, sum z x, sum x per tap (this thread's positions)
+    if (E0) {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) w1[E0 ? k : 0] = w2[E0 ? k : 0] = w3[E0 ? k : 0] = 0.0f;
+    }
     // grid (C, splits), or (splits, C) with A.swap: consecutive blocks then walk consecutive pieces of ONE channel row
     const int c = A.swap ? blockIdx.y : blockIdx.x;
     const unsigned by = A.swap ? blockIdx.x : blockIdx.y, ny = A.swap ? gridDim.x : gridDim.y;
@@ -624,7 +636,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     bool have = false;
 
     // ---- the loads of one trip
-    auto load = [&](size_t q4, PassALoads<MODE>& t) {
+    auto load = [&](size_t q4, PassALoads<MODE, E0>& t) {
         const size_t p = q4 << 2;
         t.b = (int)(p >> A.logL); t.l = (int)(p & (size_t)(A.L - 1));
         const int b = t.b, l = t.l;
@@ -668,6 +680,16 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
                 }
             } else { const float2 tt = *reinterpret_cast<const float2*>(ge); e0 = tt.x; e1 = tt.y; }
             t.e0 = e0; t.e1 = e1;
+            if (E0) {
+                // l and L are multiples of 4: an aligned 16-byte piece of the row lies wholly inside [0, L) or wholly outside (zero padding of the conv)
+                const float* xr = A.x0 + (size_t)b * A.L;
+#pragma unroll
+                for (int v = 0; v < 5; ++v) {
+                    const int lv = l - 8 + 4 * v;
+                    const bool ok = lv >= 0 && lv < A.L;
+                    t.xw[E0 ? v : 0] = wunet_sel4(ok, wunet_ld4(xr + (ok ? lv : 0)));
+                }
+            }
         } else {
             const int Lo = 2 * A.L;                               // row stride of the upsampled tensor
             const float* row = A.g0 + ((size_t)b * A.Cg0 + c) * Lo;
@@ -686,7 +708,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     };
 
     // ---- g of the trip's four samples, LeakyReLU', the sums
-    auto compute = [&](const PassALoads<MODE>& t) {
+    auto compute = [&](const PassALoads<MODE, E0>& t) {
         const int b = t.b, l = t.l;
         const wunet_f4 z = t.z;
         float g[4];
@@ -768,6 +790,22 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
             mg = fmaxf(mg, fabsf(gv));
             mz = fmaxf(mz, fabsf(zc));
         }
+        if (E0) {
+            float xs[20];
+#pragma unroll
+            for (int v = 0; v < 5; ++v) { xs[4 * v] = t.xw[E0 ? v : 0][0]; xs[4 * v + 1] = t.xw[E0 ? v : 0][1]; xs[4 * v + 2] = t.xw[E0 ? v : 0][2]; xs[4 * v + 3] = t.xw[E0 ? v : 0][3]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool pad = l + j >= A.Lt;
+                const float zz = pad ? 0.0f : z[j], one = pad ? 0.0f : 1.0f;
+#pragma unroll
+                for (int k = 0; k < 15; ++k) {                    // x[l + j + k - 7] = xs[j + k + 1]
+                    w1[E0 ? k : 0] = fmaf(go[j], xs[j + k + 1], w1[E0 ? k : 0]);
+                    w2[E0 ? k : 0] = fmaf(zz, xs[j + k + 1], w2[E0 ? k : 0]);
+                    w3[E0 ? k : 0] = fmaf(one, xs[j + k + 1], w3[E0 ? k : 0]);
+                }
+            }
+        }
         if (FUSE) { keep_g = go; keep_z = z; keep_i = t.zi; keep_l = l; have = true; }      // the thread's only trip
         else if (A.gpre) wunet_st4(A.gpre + t.zi, go);          // (nullptr: the consumer recomputes g - gz_split_h3_kernel's recompute modes)
     };
@@ -778,7 +816,7 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
     // decoder.10's geometry back to back (tools/microbench/elem_passes.hip), 36 us per step of serial kernel time, nothing on the two-stream step -
     // in the step the pass runs at what the memory system gives it behind a data gradient's 300 MB of write-backs
     for (size_t q4 = beg + threadIdx.x; q4 < end; q4 += 2 * WUNET_THREADS) {
-        PassALoads<MODE> t0, t1;
+        PassALoads<MODE, E0> t0, t1;
         const bool two = !FUSE && q4 + WUNET_THREADS < end;
         load(q4, t0);
         if (!FUSE) load(two ? q4 + WUNET_THREADS : q4, t1);
@@ -786,6 +824,22 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
         if (two) compute(t1);
     }
     const bool want_max = A.pmax != nullptr;
+    if (E0) {
+        // the block's 45 sums: 16-lane rows by DPP, the four rows of a wave by two shuffle steps, the four waves through LDS in wave order (fixed order)
+#pragma unroll
+        for (int q = 0; q < 45; ++q) {
+            float v = q < 15 ? w1[E0 ? q : 0] : q < 30 ? w2[E0 ? q - 15 : 0] : w3[E0 ? q - 30 : 0];
+            v = wunet_row16_sum(v);
+            v += wunet_shfl_xor(v, 16);
+            v += wunet_shfl_xor(v, 32);
+            if ((threadIdx.x & 63) == 0) e0x[E0 ? (threadIdx.x >> 6) * 48 + q : 0] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 45) {
+            const int q = threadIdx.x;
+            A.e0rows[((size_t)by * A.C + c) * 48 + q] = (e0x[E0 ? q : 0] + e0x[E0 ? 48 + q : 0]) + (e0x[E0 ? 96 + q : 0] + e0x[E0 ? 144 + q : 0]);
+        }
+    }
     block_reduce_pass_a(s1, s2, s3, MODE == A_HEAD, mg, mz, red);
     if (FUSE) {
         // bn_finalize_bwd_kernel's arithmetic on the (float-rounded, as if through part[]) sums, then gz_materialize_kernel's
@@ -832,6 +886,8 @@ struct BnBwdArgs {
     int C; double count;
     const float* pmax;   // nullptr or pass A's [rows][C][2] maxima
     float* bound;        // [C]: |k1| max|g| + |a m2 rstd| max|z - mean| + |a m1|  >=  max |g_z| of the channel
+    const float* e0rows; // nullptr, or the first layer's [rows][C][48] partial sums (pass_a_kernel<.., E0>): its weight gradient is finished here
+    float* dw0;          // [C][15]: dW[c][k] = k1 sum g x + k2 sum z x + k3 sum x
 };
 
 static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(BnBwdArgs A)
@@ -864,6 +920,29 @@ static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(B
         A.k2[c] = (float)(-a * m2 * (double)rs);
         A.k3[c] = (float)(a * m2 * (double)rs * (double)mu - a * m1);
         if (A.pmax) A.bound[c] = (float)(fabs(a) * (double)mg + fabs(a * m2 * (double)rs) * (double)mz + fabs(a * m1));
+    }
+    if (A.e0rows) {
+        // the first layer's weight gradient from the three sums per tap: the rows in order, in double; the coefficients as g_z would have had them
+        // (the float k1, k2, k3)
+        __shared__ double e0s[48];
+        if (tid < 45) {
+            double t = 0.0;
+            for (int r0 = 0; r0 < A.rows; r0 += 32) {          // (32 rows' loads in flight: 128 rows are four round trips on the backward's last stretch)
+                float v[32];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) v[r] = A.e0rows[((size_t)(r0 + r < A.rows ? r0 + r : 0) * A.C + c) * 48 + tid];
+#pragma unroll
+                for (int r = 0; r < 32; ++r) if (r0 + r < A.rows) t += (double)v[r];
+            }
+            e0s[tid] = t;
+        }
+        __syncthreads();
+        if (tid < 15) {
+            const double m1 = s1 / A.count, m2 = s2 / A.count;
+            const double a = (double)gam * (double)rs;
+            const float k1 = (float)a, k2 = (float)(-a * m2 * (double)rs), k3 = (float)(a * m2 * (double)rs * (double)mu - a * m1);
+            A.dw0[c * 15 + tid] = (float)((double)k1 * e0s[tid] + (double)k2 * e0s[15 + tid] + (double)k3 * e0s[30 + tid]);
+        }
     }
 }
 

@@ -123,7 +123,8 @@ struct wunet_ctx {
     std::vector<wunet_host::LayerPlan> ly;
     size_t stats_off, wpkf_off, spart_off, fwd_floats;
     size_t bmax_off, bound_off;   // pass A maxima / per-channel |g_z| bounds (fp16-split scale)
-    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, hpart2_off, total_floats;
+    size_t bpart_off, wgpart_off, wpkb_off, gh_off, hpart_off, hpart2_off, e0part_off, total_floats;
+    int e0 = 1;                   // the first layer's weight gradient from pass A's sums (pass_a_kernel<.., E0>); WUNET_NO_E0=1, read when the context is planned: off
     int head_blocks;
     int h3 = 0;                   // fp16-split GEMMs: 0 off, 1 where the planner wants them, 2 wherever they can run
     int bf = 0;                   // the split kernels run their bf16 mode (one bf16 word per operand value, one MFMA pass)

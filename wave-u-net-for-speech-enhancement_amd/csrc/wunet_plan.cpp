@@ -553,6 +553,8 @@ void layout_workspace(wunet_ctx* c)
     }
     c->hpart_off = off; off += align64((size_t)c->head_blocks * 2);
     c->hpart2_off = off; off += align64((size_t)256 * ci);          // pass A (head mode) partial head-weight gradients [a_split][ci]
+    c->e0part_off = off; off += align64((size_t)256 * ci * 48);     // pass A of the first layer (E0): its weight gradient's partial sums [a_split][ci][48]
+    c->e0 = getenv("WUNET_NO_E0") ? 0 : 1;
     // ---- fp16-split data gradient: transposed packs, one shared split g_z buffer, scale slot
     size_t wbh = 0, gzs = 0;
     for (int i = 0; i < c->NL; ++i) {
