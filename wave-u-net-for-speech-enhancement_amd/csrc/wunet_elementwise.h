@@ -802,7 +802,10 @@ __global__ __launch_bounds__(WUNET_THREADS) void pass_a_kernel(PassAArgs A)
                 for (int k = 0; k < 15; ++k) {                    // x[l + j + k - 7] = xs[j + k + 1]
                     w1[E0 ? k : 0] = fmaf(go[j], xs[j + k + 1], w1[E0 ? k : 0]);
                     w2[E0 ? k : 0] = fmaf(zz, xs[j + k + 1], w2[E0 ? k : 0]);
-                    w3[E0 ? k : 0] = fmaf(one, xs[j + k + 1], w3[E0 ? k : 0]);
+                }
+                if (c == 0) {                                     // (sum x does not depend on the channel: channel 0's blocks take it for all)
+#pragma unroll
+                    for (int k = 0; k < 15; ++k) w3[E0 ? k : 0] = fmaf(one, xs[j + k + 1], w3[E0 ? k : 0]);
                 }
             }
         }
@@ -930,7 +933,7 @@ static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(B
             for (int r0 = 0; r0 < A.rows; r0 += 32) {          // (32 rows' loads in flight: 128 rows are four round trips on the backward's last stretch)
                 float v[32];
 #pragma unroll
-                for (int r = 0; r < 32; ++r) v[r] = A.e0rows[((size_t)(r0 + r < A.rows ? r0 + r : 0) * A.C + c) * 48 + tid];
+                for (int r = 0; r < 32; ++r) v[r] = A.e0rows[((size_t)(r0 + r < A.rows ? r0 + r : 0) * A.C + (tid < 30 ? c : 0)) * 48 + tid];      // (sum x: taken by channel 0's blocks)
 #pragma unroll
                 for (int r = 0; r < 32; ++r) if (r0 + r < A.rows) t += (double)v[r];
             }
@@ -941,7 +944,7 @@ static __global__ __launch_bounds__(WUNET_THREADS) void bn_finalize_bwd_kernel(B
             const double m1 = s1 / A.count, m2 = s2 / A.count;
             const double a = (double)gam * (double)rs;
             const float k1 = (float)a, k2 = (float)(-a * m2 * (double)rs), k3 = (float)(a * m2 * (double)rs * (double)mu - a * m1);
-            A.dw0[c * 15 + tid] = (float)((double)k1 * e0s[tid] + (double)k2 * e0s[15 + tid] + (double)k3 * e0s[30 + tid]);
+            A.dw0[c * 15 + tid] = (float)((double)k1 * e0s[tid] + (double)k2 * e0s[15 + tid] + (double)k3 * e0s[30 + tid]);      // (e0s[30 ..]: channel 0's rows)
         }
     }
 }
