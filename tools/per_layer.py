@@ -1,4 +1,5 @@
-import csv, sys
+import csv, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import plan
 d=sys.argv[1]; pre=sys.argv[2]
 rows=list(csv.DictReader(open(f'{d}/{pre}_kernel_trace.csv')))
@@ -23,6 +24,6 @@ for i,(n,ci,co,t) in enumerate(layers):
     L=Ls[i]; fl=2.0*B*L*ci*co*t
     f=dur(fwd[i]); 
     d_=dur(dg[i-1]) if i>0 else 0
-    w=dur(wg[::-1][i])
+    w=dur(wg[::-1][i - (25 - len(wg))]) if i >= 25 - len(wg) else 0.0      # (the first layer's weight gradient may come from pass A's sums: no kernel)
     hb=(B*L*(ci+co)*4)/5e6  # us at 5 TB/s
-    print("%-16s %5d %4d %4d | %6.1f %5.0f %6.1f | %6.1f %5.0f | %6.1f %5.0f  %s"%(n,L,ci,co,f,tf(fl,f),hb,d_,tf(fl,d_) if i>0 else 0,w,tf(fl,w), fwd[i]['Kernel_Name'][5:28]))
+    print("%-16s %5d %4d %4d | %6.1f %5.0f %6.1f | %6.1f %5.0f | %6.1f %5.0f  %s"%(n,L,ci,co,f,tf(fl,f),hb,d_,tf(fl,d_) if i>0 else 0,w,tf(fl,w) if w else 0, fwd[i]['Kernel_Name'][5:28]))
